@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Benchmark of the low-bit FlashAttention-2 forward hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c4m|c5]
+
+A "step" is one pass of the whole operator (`lowbit_fa_qk_int8_pv_fp16_triton`: smooth-K mean + per-block
+quantisation of Q and K + fused attention) over one batch of synthetic fp16 inputs already resident in HBM.
+Default workload = BASELINE.json configs[1]: qk_int8_pv_fp16, HND, B=4 H=32 S=4096 D=64, non-causal.
+For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank processes its own batch shard of
+that size (the op is independent per (batch, head): no data-path collective) - weak scaling.
+Rank 0 prints ONE JSON line.  metric = attention TFLOP/s with the reference's FLOP formula
+4*B*H*D*S*S (halved for causal; utils/benchmark.py:212-214).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# dense MFMA peaks from /opt/skills/guides/MI355X_MICROARCH.md (Matrix cores): fp16/bf16 ~2.5 PF, int8 = 2x,
+# non-scaled fp8 = fp16 rate.  Half of the FLOPs are int8 (QK^T), half fp16/fp8 (PV) -> harmonic mix.
+PEAK_F16_TF = 2500.0
+PEAK_I8_TF = 5000.0
+PEAK_MIX_TF = 1.0 / (0.5 / PEAK_I8_TF + 0.5 / PEAK_F16_TF)  # 3333 TFLOP/s
+
+WORKLOADS = {
+    # name: (api, B, H, Hkv, S, D, layout, causal, extra kwargs, description)
+    "c2": ("int8_fp16", 4, 32, 32, 4096, 64, "HND", False, {}, "qk_int8_pv_fp16 HND B4 H32 S4096 D64 non-causal (BASELINE configs[1])"),
+    "c3": ("int8_fp16", 4, 32, 32, 16384, 128, "NHD", True, {}, "qk_int8_pv_fp16 NHD causal B4 H32 S16384 D128 (BASELINE configs[2])"),
+    "c4": ("int4_fp16", 4, 32, 32, 8192, 64, "HND", False, {"q_bits": 4}, "qk_int4_pv_fp16 HND B4 H32 S8192 D64 (BASELINE configs[3])"),
+    "c4m": ("int4_fp16", 4, 32, 32, 8192, 64, "HND", False, {"q_bits": 8}, "q_int8_k_int4 HND B4 H32 S8192 D64 (BASELINE configs[3], mixed)"),
+    "c5": ("int8_fp8", 4, 32, 32, 32768, 128, "HND", False, {}, "qk_int8_pv_fp8 B4 H32 S32768 D128 per GPU (BASELINE configs[4] = B32 over 8 GPUs)"),
+    "s8k": ("int8_fp16", 4, 32, 32, 8192, 64, "HND", False, {}, "qk_int8_pv_fp16 HND B4 H32 S8192 D64 non-causal"),
+    "s16k": ("int8_fp16", 4, 32, 32, 16384, 64, "HND", False, {}, "qk_int8_pv_fp16 HND B4 H32 S16384 D64 non-causal"),
+    "s32k": ("int8_fp16", 4, 32, 32, 32768, 64, "HND", False, {}, "qk_int8_pv_fp16 HND B4 H32 S32768 D64 non-causal"),
+    "d128": ("int8_fp16", 4, 32, 32, 4096, 128, "HND", False, {}, "qk_int8_pv_fp16 HND B4 H32 S4096 D128 non-causal"),
+    "c2c": ("int8_fp16", 4, 32, 32, 4096, 64, "HND", True, {}, "qk_int8_pv_fp16 HND B4 H32 S4096 D64 causal"),
+}
+# reference's published TFLOP/s for the exact default workload (INT8 non-causal S=4K, B4 H32 D64,
+# hardware not stated, kernel-only timing): example/draw/draw_single.py:15-16
+PUBLISHED = {"c2": 199.5, "s8k": 201.59, "s16k": 200.47, "s32k": 201.16, "c2c": 167.77}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(B, H, S, D, causal, budget_s=12.0):
+    """Naive SDPA (the repo's `manual_scaled_dot_product_attention`, src/core.py:46-69, restated in
+    oracle/lowbit_fa_oracle.py::sdpa_naive) on the host cores, fp32, on a bounded sample of (b,h) slices of the
+    same workload; the op is independent per slice so throughput extrapolates linearly."""
+    import numpy as np
+    from oracle import lowbit_fa_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:
+        threads = len(os.sched_getaffinity(0))
+    rng = np.random.default_rng(0)
+    q = rng.standard_normal((1, 1, S, D), dtype=np.float32)
+    k = rng.standard_normal((1, 1, S, D), dtype=np.float32)
+    v = rng.standard_normal((1, 1, S, D), dtype=np.float32)
+    orc.sdpa_naive(q[:, :, :256], k[:, :, :256], v[:, :, :256], is_causal=causal)  # warm BLAS threads
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.sdpa_naive(q, k, v, is_causal=causal)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= B * H:
+            break
+    flops = orc.attention_flops(1, 1, S, S, D, causal) * n
+    return {"value": round(flops / el / 1e12, 5), "unit": "TFLOP/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n} of {B * H} (batch,head) slices of the workload, fp32 naive SDPA "
+                      f"(oracle.sdpa_naive = src/core.py:46-69 restated, numpy/BLAS), {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--dist", default="normal", choices=["normal", "randint"],
+                    help="normal: q,k,v ~ N(0,1) (example/test_sageattn_operator.py:43-52); randint: the reference "
+                         "bench distribution q,k = randint(-100,100), v ~ N(0,1) (utils/benchmark.py:215-230)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="N>1: also time the RCCL all-gather of the output shards")
+    args = ap.parse_args()
+
+    import torch
+    import lowbit_quant_fa2_paddle_amd as lb
+    from lowbit_quant_fa2_paddle_amd import attn_qk_int8_per_block as attn_mod
+    from lowbit_quant_fa2_paddle_amd import _lib
+    _lib.load()  # fail loudly when the HIP library is missing
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE=1 here)")
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    api, B, H, Hkv, S, D, layout, causal, extra, desc = WORKLOADS[args.workload]
+    fn = {"int8_fp16": lb.lowbit_fa_qk_int8_pv_fp16_triton, "int4_fp16": lb.lowbit_fa_qk_int4_pv_fp16_triton,
+          "int8_fp8": lb.lowbit_fa_qk_int8_pv_fp8_cuda}[api]
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    shp_q = (B, H, S, D) if layout == "HND" else (B, S, H, D)
+    shp_k = (B, Hkv, S, D) if layout == "HND" else (B, S, Hkv, D)
+    if args.dist == "normal":
+        q = torch.randn(shp_q, generator=g, device=dev, dtype=torch.float32).half()
+        k = torch.randn(shp_k, generator=g, device=dev, dtype=torch.float32).half()
+    else:
+        q = torch.randint(-100, 100, shp_q, generator=g, device=dev).half()
+        k = torch.randint(-100, 100, shp_k, generator=g, device=dev).half()
+    v = torch.randn(shp_k, generator=g, device=dev, dtype=torch.float32).half()
+
+    def step():
+        return fn(q, k, v, tensor_layout=layout, is_causal=causal, **extra)
+
+    # per-launch timing of the dominant kernel with HIP events on the launch stream (torch's current stream)
+    attn_events = []
+
+    def hook(start, stop):
+        attn_events.append((start, stop))
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        o = step()
+    barrier()
+    attn_mod.EVENT_HOOK = hook
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        o = step()
+    barrier()
+    t1 = time.perf_counter()
+    attn_mod.EVENT_HOOK = None
+    elapsed = t1 - t0
+    if distributed:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    flops_rank = 4.0 * B * H * D * S * S / (2 if causal else 1)
+    value = world * flops_rank / (elapsed / args.steps) / 1e12
+
+    kern_ms = sum(a.elapsed_time(b) for a, b in attn_events) / max(len(attn_events), 1)
+    achieved = flops_rank / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+    peak = PEAK_MIX_TF
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per launch from rocprofv3 --pmc passes
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get(args.workload)
+        except Exception:
+            traffic = None
+
+    gather_ms = None
+    if distributed and args.gather:
+        from lowbit_quant_fa2_paddle_amd import dist as lbdist
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            lbdist.all_gather_batch(o)
+        barrier()
+        gather_ms = (time.perf_counter() - t0) / 5 * 1e3
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(B, H, S, D, causal)
+    if distributed:
+        dist.barrier()
+
+    if rank == 0:
+        out = {
+            "metric": "attention TFLOP/s, qk_int8_pv_fp16 B4 H32 D64 S=4096 fwd" if args.workload == "c2" else f"attention TFLOP/s, {desc}",
+            "value": round(value, 2),
+            "unit": "TFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": round(value / PUBLISHED[args.workload], 3) if (args.workload in PUBLISHED and world == 1) else None,
+            "dtype": "int8 (QK^T) + fp16 (PV), fp32 softmax/accumulate" if api != "int8_fp8" else "int8 (QK^T) + fp8 e4m3 (PV), fp32 softmax/accumulate",
+            "data": f"synthetic, {'q,k,v ~ N(0,1)' if args.dist == 'normal' else 'q,k = randint(-100,100), v ~ N(0,1)'} fp16, resident in HBM",
+            "config": {"workload": desc, "global_batch": B * world, "heads": H, "seq_len": S, "head_dim": D,
+                       "layout": layout, "causal": causal, "parallelism": f"batch-shard x{world} (no data-path collective)",
+                       "timed": "whole operator: smooth-K mean + per-block quant(Q,K) + fused attention",
+                       "kernel_only_tflops_per_gpu": round(achieved, 2), "fwd_latency_ms": round(ms_per_step, 4),
+                       "baseline_note": "vs_baseline = value / reference's published kernel-only TFLOP/s on unnamed NVIDIA hardware (BASELINE.md)"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "kernel": "attn_fwd_kernel", "kernel_ms": round(kern_ms, 4),
+                         "peak_note": "mixed roof 1/(0.5/5000 + 0.5/2500): half the FLOPs int8 MFMA, half fp16 MFMA"},
+            "cpu_baseline": cpu,
+        }
+        if gather_ms is not None:
+            out["config"]["allgather_ms"] = round(gather_ms, 3)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

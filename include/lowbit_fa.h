@@ -1,0 +1,133 @@
+/*
+ * lowbit_fa.h - C ABI of liblowbit_fa_hip.so: low-bit FlashAttention-2 forward for MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the reference's native layer.  The reference binds its native
+ * code through two pybind11 modules that take torch tensors:
+ *     _qattn  (12 functions, csrc/qattn/pybind.cpp:21-38)   - fused attention
+ *     _fused  ( 8 functions, csrc/fused/pybind.cpp:21-33)   - quantisation / pre-processing
+ * and, on the path that actually runs, through Triton launches made by Python host wrappers
+ * (src/triton/quant_per_block.py:181-248, src/triton/attn_qk_int8_per_block.py:169-238,
+ * src/triton/attn_qk_int8_per_block_causal.py:337-437).  The entry points below carry the same
+ * information across a plain C boundary: raw device pointers, sizes, element strides, a stream.
+ *
+ * Conventions (same as the reference's native layer):
+ *   - the CALLER allocates every output (csrc/qattn: `o`, src/quant.py:70-85: int8 buffers, scales);
+ *   - layouts (HND / NHD) are expressed ONLY through strides, exactly as the Triton host wrappers do
+ *     (attn_qk_int8_per_block.py:183-196); strides are in ELEMENTS: {batch, head, sequence};
+ *     the last (head_dim) stride must be 1 (src/core.py:288-290);
+ *   - every call only enqueues work on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream, which is where the reference launches, qk_int_sv_f8_cuda.cu:845); no host sync;
+ *   - no global mutable state: safe to call concurrently on different devices / streams;
+ *   - return 0 on success, non-zero LBFA_E* on failure; `lbfa_last_error()` returns a thread-local
+ *     message (the reference raises through TORCH_CHECK, csrc/utils.cuh:19-37, and
+ *     std::invalid_argument for unsupported head_dim/flags, csrc/dispatch_utils.h:23-34).
+ *
+ * Quantisation granularity is the reference Triton path's: one fp32 scale per 128 query rows
+ * (BLKQ) and per 64 key rows (BLKK) (src/triton/quant_per_block.py:182).
+ */
+#ifndef LOWBIT_FA_H_
+#define LOWBIT_FA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBFA_VERSION 100 /* 0.1.0 */
+
+/* element types */
+#define LBFA_F16 0
+#define LBFA_BF16 1
+#define LBFA_E4M3 2 /* OCP e4m3fn (gfx950 native), only as v_dtype of lbfa_attn_fwd */
+
+/* status codes */
+#define LBFA_OK 0
+#define LBFA_EINVAL 1   /* bad argument (unsupported head_dim, dtype, null pointer ...) */
+#define LBFA_ELAUNCH 2  /* HIP launch / runtime error */
+
+#define LBFA_BLKQ 128 /* query rows per scale   (src/triton/quant_per_block.py:182, attn BLOCK_M :179) */
+#define LBFA_BLKK 64  /* key rows per scale     (src/triton/quant_per_block.py:182, attn BLOCK_N :180) */
+
+int lbfa_version(void);
+
+/* Thread-local description of the last failure on this thread ("" if none). */
+const char* lbfa_last_error(void);
+
+/*
+ * Mean over the sequence of x[B,H,S,D] -> mean_out[B,H,D] (contiguous, same dtype as x).
+ * Replaces `km = k.mean(dim=seq_dim, keepdim=True)` (src/core.py:292-293); fp32 accumulation in a
+ * fixed order (deterministic), rounded once to the storage dtype.
+ * workspace: >= lbfa_mean_seq_workspace_bytes(B,H,S,D) bytes of device memory (fp32 partial sums).
+ */
+size_t lbfa_mean_seq_workspace_bytes(int B, int H, int S, int D);
+int lbfa_mean_seq(const void* x, int dtype, void* mean_out, void* workspace, size_t workspace_bytes,
+                  int B, int H, int S, int D, const int64_t strides_x[3], void* stream);
+
+/*
+ * Per-block symmetric quantisation of x[B,H,S,D] (fp16/bf16) to int8 codes + one fp32 scale per
+ * (b, h, block of `blk` rows).  Replaces the two launches of
+ * `quant_per_block_int8_kernel` (src/triton/quant_per_block.py:132-178, launched :213-247) and, with
+ * qmax = 7, `quant_per_block_int4_unpack_kernel` (:22-71) - one 4-bit-range value per int8 byte:
+ *     x' = dtype(x - mean)            (only if mean != NULL; `k = k - km`, :186-187)
+ *     xs = fp32(x') * sm_scale ; scale = max(max|xs|, 1e-7) / qmax
+ *     code = trunc(xs / scale + 0.5*sign)      (round half away from zero, :174-176)
+ * The 1e-7 floor is the CUDA quantiser's (csrc/fused/fused.cu:147); the Triton kernel has none and
+ * produces NaN on an all-zero block.  Identical bits whenever max|xs| >= 1e-7.
+ *   mean      : [B, H_mean, D] contiguous in x's dtype, or NULL.  H_mean = H / mean_group.
+ *   out       : int8, strides_out (elements); scale: [B, H, ceil(S/blk)] contiguous fp32.
+ *   rowdot_vec: optional [B, H/rowdot_group, D] (x's dtype).  When non-NULL, rowdot_out[B,H,S] (fp32,
+ *               contiguous) receives dtype(sum_d x[b,h,s,d] * vec[b,h/rowdot_group,d]) of the
+ *               UN-shifted, un-scaled x: the `lse_correction = q @ km^T` of src/core.py:294-304.
+ *   qmax in {127, 7}; blk in {128, 64}; D in {64, 128}.
+ */
+int lbfa_quant_per_block(const void* x, int dtype, const void* mean, int mean_group, int8_t* out, float* scale,
+                         float sm_scale, int qmax, int blk, int B, int H, int S, int D,
+                         const int64_t strides_x[3], const int64_t strides_out[3],
+                         const void* rowdot_vec, int rowdot_group, float* rowdot_out, void* stream);
+
+/*
+ * Per-channel FP8 quantisation of V[B,H,S,D] (fp16/bf16).  Replaces `per_channel_fp8`
+ * (src/quant.py:210-291 -> TransposePadPermuteKernel + MeanScaleKernel, csrc/fused/fused.cu:263-428):
+ *     v_scale[b,h,d] = max(max_s |v|, 1e-7) / 448 ; v_fp8 = e4m3fn_rn_sat(v * 448 / amax)
+ * v_fp8 is written in the device layout lbfa_attn_fwd consumes for v_dtype = LBFA_E4M3:
+ * [B, H, ceil(S/64), D, 64] bytes - per 64-key tile, channel-major, keys permuted for the MFMA
+ * operand (the reference likewise transposes, pads to 64 and permutes for its mma fragment,
+ * fused.cu:288-292; the permutation is a device detail, not API).
+ *   v_fp8 bytes required: lbfa_v_fp8_bytes(B,H,S,D).  Padded keys are written as 0.
+ */
+size_t lbfa_v_fp8_bytes(int B, int H, int S, int D);
+int lbfa_quant_v_fp8(const void* v, int dtype, uint8_t* v_fp8, float* v_scale, int B, int H, int S, int D,
+                     const int64_t strides_v[3], void* stream);
+
+/*
+ * Fused attention forward: O = softmax(dequant(Q K^T)) V, FlashAttention-2 tiling, online softmax in
+ * base 2 (sm_scale*log2e is already folded into q_scale by the quantiser).  Replaces
+ * `_attn_fwd` (src/triton/attn_qk_int8_per_block.py:69-167), its causal twin
+ * (src/triton/attn_qk_int8_per_block_causal.py:82-214), the int4 copies
+ * (src/triton/quantization/attn_qk_int4_per_block{,_causal}.py) and, for v_dtype = LBFA_E4M3,
+ * `qk_int8_sv_f8_accum_f32_fuse_v_scale_attn*` (csrc/qattn/qk_int_sv_f8_cuda.cu:46-692).
+ *   q [B,Hq,Sq,D], k [B,Hkv,Sk,D] : int8 codes (any range within int8: 127 or 7)
+ *   v : LBFA_F16 / LBFA_BF16 [B,Hkv,Sk,D] with strides_v (bf16 is converted to fp16 on the way into
+ *       LDS, replacing the `v.to(float16)` pass of src/core.py:307-308), or LBFA_E4M3 in the layout of
+ *       lbfa_quant_v_fp8 (strides_v ignored) together with v_scale [B,Hkv,D].
+ *   o : [B,Hq,Sq,D] fp16 or bf16 (o_dtype), strides_o.
+ *   lse : NULL, or [B,Hq,Sq] contiguous fp32 receiving log2(l) + m (base-2 domain, exactly what the
+ *         reference kernel stores, :164-167; the host converts it, src/core.py:344-350).
+ *   q_scale [B,Hq,ceil(Sq/128)], k_scale [B,Hkv,ceil(Sk/64)] contiguous fp32.
+ *   is_causal requires Sq == Sk (attn_qk_int8_per_block_causal.py:389).
+ *   Keys >= Sk are masked with -inf (the CUDA path's behaviour, csrc/qattn/attn_utils.cuh:327-353; the
+ *   Triton kernel lets them into the softmax as zeros, a defect that only shows when Sk % 64 != 0).
+ *   D in {64, 128}; Hq % Hkv == 0.
+ */
+int lbfa_attn_fwd(const int8_t* q, const int8_t* k, const void* v, int v_dtype, void* o, int o_dtype, float* lse,
+                  const float* q_scale, const float* k_scale, const float* v_scale,
+                  int B, int Hq, int Hkv, int Sq, int Sk, int D,
+                  const int64_t strides_q[3], const int64_t strides_k[3], const int64_t strides_v[3],
+                  const int64_t strides_o[3], int is_causal, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOWBIT_FA_H_ */

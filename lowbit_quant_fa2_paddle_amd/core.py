@@ -1,0 +1,247 @@
+"""Public operator API - drop-in for the reference's `src/core.py` (names, arguments, defaults, error
+behaviour), backed by hand-written gfx950 HIP kernels behind the C ABI of include/lowbit_fa.h.
+
+Reference surface (src/__init__.py:1-17, aliases src/core.py:1099-1105):
+    sageattn, sageattn_varlen, sageattn_qk_int8_pv_fp16_triton, sageattn_qk_int8_pv_fp16_cuda,
+    sageattn_qk_int8_pv_fp8_cuda, sageattn_qk_int4_pv_fp16_triton, sageattn_multi_precision and the
+    lowbit_fa_* aliases.
+The `_triton` / `_cuda` suffixes name the reference's back ends; here every entry point runs the one
+HIP back end (per-block scales, fp32 PV accumulation).  Back-end selectors (`quantization_backend`,
+`qk_quant_gran`, `pv_accum_dtype`, `smooth_v`) are accepted and validated as the reference does
+(src/core.py:320, :588-591, :721) and otherwise have no effect.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Any, Optional
+
+from . import attn_qk_int8_per_block as _attn
+from . import quant as _quant
+from . import quant_per_block as _qpb
+from ._tensor import ops_for
+
+_LOG2E = 1.44269504  # the literal of src/core.py:347
+
+
+# ------------------------------------------------------------------------------------------------------
+# shared prologue / epilogue (src/core.py:269-310, :343-350 - identical in all four reference operators)
+# ------------------------------------------------------------------------------------------------------
+def _check_inputs(q, k, v):
+    ops = ops_for(q)
+    dtype = q.dtype
+    assert ops.dtype_code(q) is not None, "Input tensors must be in dtype of torch.float16 or torch.bfloat16"
+    assert ops.same_device(q, k, v), "All tensors must be on the same device."
+    assert q.dtype == k.dtype == v.dtype, "All tensors must have the same dtype."
+    if not ops.is_gpu(q):
+        raise RuntimeError("lowbit_fa operators run on an AMD GPU (gfx950) only; got a CPU tensor. "
+                           "There is no CPU fallback.")
+    return ops, dtype
+
+
+def _pad_head_dim(ops, q, k, v):
+    head_dim_og = ops.shape(q)[-1]
+    if head_dim_og < 64:
+        pad = 64 - head_dim_og
+    elif 64 < head_dim_og < 128:
+        pad = 128 - head_dim_og
+    elif head_dim_og > 128:
+        raise ValueError(f"Unsupported head_dim: {head_dim_og}")
+    else:
+        pad = 0
+    if pad:
+        q, k, v = ops.pad_last(q, pad), ops.pad_last(k, pad), ops.pad_last(v, pad)
+    assert ops.strides(q)[-1] == 1 and ops.strides(k)[-1] == 1 and ops.strides(v)[-1] == 1, \
+        "Last dim of qkv must be contiguous."
+    return q, k, v, head_dim_og
+
+
+def _low_bit_attention(q, k, v, *, tensor_layout, is_causal, sm_scale, smooth_k, return_lse, q_qmax, k_qmax, pv):
+    """The path of `sageattn_qk_int8_pv_fp16_triton` (src/core.py:269-352), parameterised on the code
+    range of Q / K and the PV precision."""
+    ops, dtype = _check_inputs(q, k, v)
+    if tensor_layout not in ("HND", "NHD"):
+        raise ValueError(f"Unknown tensor layout: {tensor_layout}")
+    q, k, v, head_dim_og = _pad_head_dim(ops, q, k, v)
+    if sm_scale is None:
+        sm_scale = 1.0 / head_dim_og ** 0.5  # ORIGINAL head dim (:309-310)
+    km = _qpb.mean_seq(k, tensor_layout) if smooth_k else None  # :292-293
+    # Q: sm_scale*log2e folded in (quant_per_block.py:226).  With smooth_k + return_lse the same launch
+    # also produces lse_correction = q . km (:294-304).
+    want_corr = smooth_k and return_lse
+    qres = _qpb.quantize(q, sm_scale=sm_scale * _LOG2E, qmax=q_qmax, blk=128, tensor_layout=tensor_layout,
+                         rowdot_vec=km if want_corr else None)
+    q_int8, q_scale = qres[0], qres[1]
+    lse_correction = qres[2] if want_corr else None
+    k_int8, k_scale = _qpb.quantize(k, sm_scale=1.0, qmax=k_qmax, blk=64, tensor_layout=tensor_layout, mean=km)
+    if pv == "fp8":
+        v_in, v_scale, _ = _quant.per_channel_fp8(v, tensor_layout=tensor_layout)
+    else:
+        v_in, v_scale = v, None  # bf16 V is converted to fp16 inside the kernel (replaces :307-308)
+    o, lse = _attn.forward(q_int8, k_int8, v_in, q_scale, k_scale, tensor_layout=tensor_layout, output_dtype=dtype,
+                           return_lse=return_lse, is_causal=is_causal, v_scale=v_scale)
+    o = o[..., :head_dim_og]
+    if return_lse:
+        lse = lse / _LOG2E
+        if smooth_k:
+            lse = lse + lse_correction * sm_scale
+        return o, lse
+    return o
+
+
+# ------------------------------------------------------------------------------------------------------
+# operators
+# ------------------------------------------------------------------------------------------------------
+def sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout: str = "HND", quantization_backend: str = "triton",
+                                    is_causal: bool = False, sm_scale: Optional[float] = None, smooth_k: bool = True,
+                                    return_lse: bool = False, **kwargs: Any):
+    """Per-block INT8 Q/K, FP16 PV (reference: src/core.py:194-352).
+
+    q: [B, Hq, Sq, D] ("HND") or [B, Sq, Hq, D] ("NHD"); k, v likewise with Hkv | Hq; fp16 or bf16.
+    Returns o (same shape/dtype as q) and, if `return_lse`, the natural-log LSE [B, Hq, Sq] fp32.
+    """
+    if quantization_backend not in ("triton", "cuda"):
+        raise ValueError(f"Unsupported quantization backend: {quantization_backend}")  # :320
+    return _low_bit_attention(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal, sm_scale=sm_scale,
+                              smooth_k=smooth_k, return_lse=return_lse, q_qmax=127, k_qmax=127, pv="fp16")
+
+
+def sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout: str = "HND", is_causal: bool = False,
+                                  qk_quant_gran: str = "per_thread", sm_scale: Optional[float] = None,
+                                  pv_accum_dtype: str = "fp32", smooth_k: bool = True, smooth_v: bool = False,
+                                  return_lse: bool = False, **kwargs: Any):
+    """INT8 Q/K, FP16 PV (reference: src/core.py:495-731).  `qk_quant_gran` and `pv_accum_dtype` pick among
+    NVIDIA-fragment-specific variants in the reference; validated, then the per-block / fp32-accumulate
+    HIP kernel runs."""
+    assert qk_quant_gran in ["per_warp", "per_thread"], "qk_quant_gran must be either 'per_warp' or 'per_thread'."
+    if pv_accum_dtype not in ("fp32", "fp16", "fp16+fp32"):
+        raise ValueError(f"Unsupported pv_accum_dtype: {pv_accum_dtype}")  # :721
+    if pv_accum_dtype in ["fp32", "fp16+fp32"] and smooth_v:
+        warnings.warn(f"pv_accum_dtype is {pv_accum_dtype}, smooth_v will be ignored.")  # :642-644
+    return _low_bit_attention(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal, sm_scale=sm_scale,
+                              smooth_k=smooth_k, return_lse=return_lse, q_qmax=127, k_qmax=127, pv="fp16")
+
+
+def sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout: str = "HND", is_causal: bool = False,
+                                 qk_quant_gran: str = "per_thread", sm_scale: Optional[float] = None,
+                                 pv_accum_dtype: str = "fp32+fp32", smooth_k: bool = True, smooth_v: bool = False,
+                                 return_lse: bool = False, **kwargs: Any):
+    """INT8 Q/K, FP8 (e4m3) P and V with per-channel V scales, fp32 accumulation
+    (reference: src/core.py:735-941; kernel semantics csrc/qattn/qk_int_sv_f8_cuda.cu)."""
+    assert qk_quant_gran in ["per_warp", "per_thread"], "qk_quant_gran must be either 'per_warp' or 'per_thread'."
+    if pv_accum_dtype not in ("fp32", "fp32+fp32"):
+        raise ValueError(f"Unsupported pv_accum_dtype: {pv_accum_dtype}")
+    if pv_accum_dtype == "fp32+fp32" and smooth_v:
+        warnings.warn("pv_accum_dtype is 'fp32+fp32', smooth_v will be ignored.")  # :879-881
+    return _low_bit_attention(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal, sm_scale=sm_scale,
+                              smooth_k=smooth_k, return_lse=return_lse, q_qmax=127, k_qmax=127, pv="fp8")
+
+
+def sageattn_qk_int4_pv_fp16_triton(q, k, v, tensor_layout: str = "HND", quantization_backend: str = "triton",
+                                    is_causal: bool = False, sm_scale: Optional[float] = None, smooth_k: bool = True,
+                                    return_lse: bool = False, q_bits: int = 4, **kwargs: Any):
+    """4-bit-range Q/K codes, FP16 PV (reference API: src/core.py:945-1036).
+
+    The reference body feeds a group-wise asymmetric packer's output to a kernel that expects per-block
+    symmetric codes and cannot run; the arithmetic implemented is what its kernels define:
+    `quant_per_block_int4_unpack_kernel` (+-7 codes, one per byte) + the int8 tile loop.
+    `q_bits=4` (default): Q and K both +-7 ("qk_int4", what the function name and the int4 bench use);
+    `q_bits=8`: Q +-127, K +-7 ("q_int8_k_int4", the bit widths the reference body passes, :999-1004).
+    """
+    if q_bits not in (4, 8):
+        raise ValueError(f"q_bits must be 4 or 8, got {q_bits}")
+    return _low_bit_attention(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal, sm_scale=sm_scale,
+                              smooth_k=smooth_k, return_lse=return_lse, q_qmax=7 if q_bits == 4 else 127, k_qmax=7,
+                              pv="fp16")
+
+
+def sageattn(q, k, v, tensor_layout: str = "HND", is_causal: bool = False, sm_scale: Optional[float] = None,
+             return_lse: bool = False, **kwargs: Any):
+    """Auto-dispatcher (reference: src/core.py:82-190 maps sm80/86/89/90 to a kernel family).  On gfx950 the
+    headline INT8-QK / FP16-PV kernel is selected."""
+    return sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal,
+                                           sm_scale=sm_scale, return_lse=return_lse, **kwargs)
+
+
+def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_seqlen_k: int,
+                    is_causal: bool = False, sm_scale: Optional[float] = None, smooth_k: bool = True, **kwargs: Any):
+    """Variable-length batch (reference: src/core.py:356-491): q [sum_q, Hq, D], k/v [sum_k, Hkv, D], cu_seqlens
+    int32 [B+1].  Each sequence is an independent attention problem (smooth-K mean is per sequence in the
+    reference too, quant_per_block_varlen.py); sequences are dispatched one by one as NHD batches of 1 onto the
+    dense kernel and written into one packed output."""
+    ops = ops_for(q)
+    cq = [int(x) for x in cu_seqlens_q.tolist()]
+    ck = [int(x) for x in cu_seqlens_k.tolist()]
+    if len(cq) != len(ck):
+        raise ValueError("cu_seqlens_q and cu_seqlens_k must have the same length")
+    outs = []
+    for i in range(len(cq) - 1):
+        qi, ki, vi = q[cq[i]:cq[i + 1]], k[ck[i]:ck[i + 1]], v[ck[i]:ck[i + 1]]
+        oi = sageattn_qk_int8_pv_fp16_triton(qi[None], ki[None], vi[None], tensor_layout="NHD", is_causal=is_causal,
+                                             sm_scale=sm_scale, smooth_k=smooth_k)
+        outs.append(oi[0])
+    return ops.cat0(outs)
+
+
+def manual_scaled_dot_product_attention(q, k, v, is_causal=False):
+    """The reference's FP16 fall-back (src/core.py:46-69) with the intended K^T (the `[0,2,3,1]` transpose at
+    :55 is a defect).  Plain framework matmuls in the input dtype: this is the un-quantised
+    branch of `sageattn_multi_precision`, not part of the low-bit hot path."""
+    ops = ops_for(q)
+    if ops.name != "torch":  # pragma: no cover
+        import paddle
+        scale = q.shape[-1] ** -0.5
+        scores = paddle.matmul(q, k.transpose([0, 1, 3, 2])) * scale
+        if is_causal:
+            n = scores.shape[-1]
+            scores = scores + (1 - paddle.tril(paddle.ones((n, n), dtype=scores.dtype))) * -1e9
+        return paddle.matmul(paddle.nn.functional.softmax(scores, axis=-1), v)
+    torch = ops.torch
+    scale = q.shape[-1] ** -0.5
+    scores = torch.matmul(q, k.transpose(-1, -2)) * scale
+    if is_causal:
+        n = scores.shape[-1]
+        scores = scores + (1 - torch.tril(torch.ones((n, n), dtype=scores.dtype, device=scores.device))) * -1e9
+    return torch.matmul(torch.softmax(scores, dim=-1), v)
+
+
+default_attn = manual_scaled_dot_product_attention
+
+
+def compute_scale(tensor, bits=8, symmetric=True):
+    """src/core.py:1039-1048: per-tensor scale max|x| / (2^(bits-1) - 1) (or (max-min)/(2^bits-1))."""
+    if symmetric:
+        return tensor.abs().max() / (2 ** (bits - 1) - 1)
+    return (tensor.max() - tensor.min()) / (2 ** bits - 1)
+
+
+def select_quantization(q, k, v):
+    """src/core.py:1051-1063: average per-tensor scale > 0.2 -> FP16, > 0.05 -> INT8, else INT4."""
+    avg_scale = float((compute_scale(q, bits=8) + compute_scale(k, bits=8) + compute_scale(v, bits=8)) / 3.0)
+    if avg_scale > 0.2:
+        return "FP16"
+    if avg_scale > 0.05:
+        return "INT8"
+    return "INT4"
+
+
+def sageattn_multi_precision(q, k, v, tensor_layout: str = "HND", is_causal: bool = False,
+                             sm_scale: Optional[float] = None, return_lse: bool = False, **kwargs: Any):
+    """Importance-aware precision router (reference: src/core.py:1066-1096)."""
+    kind = select_quantization(q, k, v)
+    if kind == "FP16":
+        return default_attn(q, k, v, is_causal=is_causal)
+    if kind == "INT8":
+        return sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal,
+                                               sm_scale=sm_scale, return_lse=return_lse)
+    return sageattn_qk_int4_pv_fp16_triton(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal,
+                                           sm_scale=sm_scale, return_lse=return_lse)
+
+
+# Aliases with the preferred naming (src/core.py:1099-1105)
+lowbit_fa_attn = sageattn
+lowbit_fa_varlen = sageattn_varlen
+lowbit_fa_multi_precision = sageattn_multi_precision
+lowbit_fa_qk_int8_pv_fp16_triton = sageattn_qk_int8_pv_fp16_triton
+lowbit_fa_qk_int8_pv_fp16_cuda = sageattn_qk_int8_pv_fp16_cuda
+lowbit_fa_qk_int8_pv_fp8_cuda = sageattn_qk_int8_pv_fp8_cuda
+lowbit_fa_qk_int4_pv_fp16_triton = sageattn_qk_int4_pv_fp16_triton

@@ -1,0 +1,160 @@
+// extern "C" entry points of liblowbit_fa_hip.so (declared in include/lowbit_fa.h).
+// Argument validation mirrors the reference's checks (src/core.py:269-290, csrc/utils.cuh:19-37,
+// csrc/dispatch_utils.h:23-34); failures return a status code and leave a thread-local message.
+#include <cstdarg>
+#include <cstdio>
+
+#include "lbfa_common.h"
+
+namespace lbfa {
+// defined in quant_kernels.hip / attn_fwd.hip
+int mean_rows_per_split(int S);
+size_t v_fp8_payload_bytes(int B, int H, int S, int D);
+hipError_t launch_mean_seq(const void* x, int dtype, void* out, void* ws, int B, int H, int S, int D,
+                           const int64_t* st, hipStream_t stream);
+hipError_t launch_quant_per_block(const QuantParams& p, int dtype, int D, int blk, hipStream_t stream);
+hipError_t launch_quant_v_fp8(const void* v, int dtype, uint8_t* out, float* v_scale, int B, int H, int S, int D,
+                              const int64_t* st, hipStream_t stream);
+hipError_t launch_attn_fwd(const AttnParams& p, int D, int v_dtype, int o_dtype, int causal, hipStream_t stream);
+}  // namespace lbfa
+
+namespace {
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return LBFA_OK;
+  return fail(LBFA_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+}
+bool dims_ok(int B, int H, int S, int D) { return B > 0 && H > 0 && S > 0 && (D == 64 || D == 128); }
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+}  // namespace
+
+extern "C" {
+
+int lbfa_version(void) { return LBFA_VERSION; }
+
+const char* lbfa_last_error(void) { return g_err; }
+
+size_t lbfa_mean_seq_workspace_bytes(int B, int H, int S, int D) {
+  if (B <= 0 || H <= 0 || S <= 0 || D <= 0) return 0;
+  const int rps = lbfa::mean_rows_per_split(S);
+  const size_t nsplit = (size_t)(S + rps - 1) / rps;
+  return (size_t)B * H * nsplit * D * sizeof(float);
+}
+
+int lbfa_mean_seq(const void* x, int dtype, void* mean_out, void* workspace, size_t workspace_bytes,
+                  int B, int H, int S, int D, const int64_t strides_x[3], void* stream) {
+  if (!x || !mean_out || !workspace || !strides_x) return fail(LBFA_EINVAL, "lbfa_mean_seq: null pointer");
+  if (!dims_ok(B, H, S, D)) return fail(LBFA_EINVAL, "Unsupported head_dim: %d (or empty tensor %dx%dx%d)", D, B, H, S);
+  if (dtype != LBFA_F16 && dtype != LBFA_BF16)
+    return fail(LBFA_EINVAL, "Input tensors must be in dtype of float16 or bfloat16");
+  if (workspace_bytes < lbfa_mean_seq_workspace_bytes(B, H, S, D)) return fail(LBFA_EINVAL, "lbfa_mean_seq: workspace too small");
+  if (!aligned16(x) || (strides_x[0] | strides_x[1] | strides_x[2]) % 8 != 0)
+    return fail(LBFA_EINVAL, "lbfa_mean_seq: x must be 16-byte aligned with strides that are multiples of 8 elements");
+  g_err[0] = 0;
+  return check_hip(lbfa::launch_mean_seq(x, dtype, mean_out, workspace, B, H, S, D, strides_x, (hipStream_t)stream),
+                   "lbfa_mean_seq launch");
+}
+
+int lbfa_quant_per_block(const void* x, int dtype, const void* mean, int mean_group, int8_t* out, float* scale,
+                         float sm_scale, int qmax, int blk, int B, int H, int S, int D,
+                         const int64_t strides_x[3], const int64_t strides_out[3],
+                         const void* rowdot_vec, int rowdot_group, float* rowdot_out, void* stream) {
+  if (!x || !out || !scale || !strides_x || !strides_out) return fail(LBFA_EINVAL, "lbfa_quant_per_block: null pointer");
+  if (!dims_ok(B, H, S, D)) return fail(LBFA_EINVAL, "Unsupported head_dim: %d (or empty tensor %dx%dx%d)", D, B, H, S);
+  if (dtype != LBFA_F16 && dtype != LBFA_BF16)
+    return fail(LBFA_EINVAL, "Input tensors must be in dtype of float16 or bfloat16");
+  if (qmax != 127 && qmax != 7) return fail(LBFA_EINVAL, "lbfa_quant_per_block: qmax must be 127 (int8) or 7 (int4 range), got %d", qmax);
+  if (blk != 128 && blk != 64) return fail(LBFA_EINVAL, "lbfa_quant_per_block: blk must be 128 or 64, got %d", blk);
+  if (mean && (mean_group <= 0 || H % mean_group != 0)) return fail(LBFA_EINVAL, "lbfa_quant_per_block: bad mean_group %d for H=%d", mean_group, H);
+  if (rowdot_vec && (!rowdot_out || rowdot_group <= 0 || H % rowdot_group != 0))
+    return fail(LBFA_EINVAL, "lbfa_quant_per_block: rowdot_vec needs rowdot_out and a rowdot_group dividing H");
+  if (!aligned16(x) || (strides_x[0] | strides_x[1] | strides_x[2]) % 8 != 0)
+    return fail(LBFA_EINVAL, "lbfa_quant_per_block: x must be 16-byte aligned with strides that are multiples of 8 elements");
+  if ((reinterpret_cast<uintptr_t>(out) & 7u) || (strides_out[0] | strides_out[1] | strides_out[2]) % 8 != 0)
+    return fail(LBFA_EINVAL, "lbfa_quant_per_block: out must be 8-byte aligned with strides that are multiples of 8");
+  lbfa::QuantParams p;
+  p.x = (const unsigned short*)x;
+  p.mean = (const unsigned short*)mean;
+  p.out = out;
+  p.scale = scale;
+  p.rowdot_vec = (const unsigned short*)rowdot_vec;
+  p.rowdot_out = rowdot_out;
+  p.xb = strides_x[0]; p.xh = strides_x[1]; p.xs = strides_x[2];
+  p.ob = strides_out[0]; p.oh = strides_out[1]; p.os = strides_out[2];
+  p.sm_scale = sm_scale;
+  p.qmax = (float)qmax;
+  p.B = B; p.H = H; p.S = S;
+  p.nblk = (S + blk - 1) / blk;
+  p.mean_group = mean ? mean_group : 1;
+  p.rowdot_group = rowdot_vec ? rowdot_group : 1;
+  g_err[0] = 0;
+  return check_hip(lbfa::launch_quant_per_block(p, dtype, D, blk, (hipStream_t)stream), "lbfa_quant_per_block launch");
+}
+
+size_t lbfa_v_fp8_bytes(int B, int H, int S, int D) {
+  if (B <= 0 || H <= 0 || S <= 0 || D <= 0) return 0;
+  // payload [B,H,ceil(S/64),D,64] + fp32 amax scratch [B,H,D]
+  return lbfa::v_fp8_payload_bytes(B, H, S, D) + (size_t)B * H * D * sizeof(float);
+}
+
+int lbfa_quant_v_fp8(const void* v, int dtype, uint8_t* v_fp8, float* v_scale, int B, int H, int S, int D,
+                     const int64_t strides_v[3], void* stream) {
+  if (!v || !v_fp8 || !v_scale || !strides_v) return fail(LBFA_EINVAL, "lbfa_quant_v_fp8: null pointer");
+  if (!dims_ok(B, H, S, D)) return fail(LBFA_EINVAL, "Unsupported head_dim: %d (or empty tensor %dx%dx%d)", D, B, H, S);
+  if (dtype != LBFA_F16 && dtype != LBFA_BF16)
+    return fail(LBFA_EINVAL, "Input tensors must be in dtype of float16 or bfloat16");
+  if (!aligned16(v) || !aligned16(v_fp8) || (strides_v[0] | strides_v[1] | strides_v[2]) % 8 != 0)
+    return fail(LBFA_EINVAL, "lbfa_quant_v_fp8: v / v_fp8 must be 16-byte aligned, strides multiples of 8 elements");
+  g_err[0] = 0;
+  return check_hip(lbfa::launch_quant_v_fp8(v, dtype, v_fp8, v_scale, B, H, S, D, strides_v, (hipStream_t)stream),
+                   "lbfa_quant_v_fp8 launch");
+}
+
+int lbfa_attn_fwd(const int8_t* q, const int8_t* k, const void* v, int v_dtype, void* o, int o_dtype, float* lse,
+                  const float* q_scale, const float* k_scale, const float* v_scale,
+                  int B, int Hq, int Hkv, int Sq, int Sk, int D,
+                  const int64_t strides_q[3], const int64_t strides_k[3], const int64_t strides_v[3],
+                  const int64_t strides_o[3], int is_causal, void* stream) {
+  if (!q || !k || !v || !o || !q_scale || !k_scale || !strides_q || !strides_k || !strides_o)
+    return fail(LBFA_EINVAL, "lbfa_attn_fwd: null pointer");
+  if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Sk <= 0) return fail(LBFA_EINVAL, "lbfa_attn_fwd: empty tensor");
+  if (D != 64 && D != 128) return fail(LBFA_EINVAL, "Unsupported head_dim: %d", D);
+  if (Hq % Hkv != 0) return fail(LBFA_EINVAL, "num_qo_heads (%d) must be divisible by num_kv_heads (%d)", Hq, Hkv);
+  if (v_dtype != LBFA_F16 && v_dtype != LBFA_BF16 && v_dtype != LBFA_E4M3) return fail(LBFA_EINVAL, "lbfa_attn_fwd: bad v_dtype %d", v_dtype);
+  if (o_dtype != LBFA_F16 && o_dtype != LBFA_BF16) return fail(LBFA_EINVAL, "lbfa_attn_fwd: bad o_dtype %d", o_dtype);
+  if (v_dtype == LBFA_E4M3 && !v_scale) return fail(LBFA_EINVAL, "lbfa_attn_fwd: v_scale is required for fp8 V");
+  if (v_dtype != LBFA_E4M3 && !strides_v) return fail(LBFA_EINVAL, "lbfa_attn_fwd: strides_v is required for fp16/bf16 V");
+  if (is_causal && Sq != Sk) return fail(LBFA_EINVAL, "qo_len and kv_len must be equal for causal attention");
+  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (reinterpret_cast<uintptr_t>(o) & 7u))
+    return fail(LBFA_EINVAL, "lbfa_attn_fwd: q/k/v must be 16-byte aligned and o 8-byte aligned");
+  if ((strides_q[0] | strides_q[1] | strides_q[2] | strides_k[0] | strides_k[1] | strides_k[2]) % 16 != 0)
+    return fail(LBFA_EINVAL, "lbfa_attn_fwd: q/k strides must be multiples of 16 elements");
+  if (v_dtype != LBFA_E4M3 && (strides_v[0] | strides_v[1] | strides_v[2]) % 8 != 0)
+    return fail(LBFA_EINVAL, "lbfa_attn_fwd: v strides must be multiples of 8 elements");
+  if ((strides_o[0] | strides_o[1] | strides_o[2]) % 4 != 0) return fail(LBFA_EINVAL, "lbfa_attn_fwd: o strides must be multiples of 4 elements");
+  lbfa::AttnParams p;
+  p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse;
+  p.q_scale = q_scale; p.k_scale = k_scale; p.v_scale = v_scale;
+  p.qb = strides_q[0]; p.qh = strides_q[1]; p.qs = strides_q[2];
+  p.kb = strides_k[0]; p.kh = strides_k[1]; p.ks = strides_k[2];
+  if (v_dtype != LBFA_E4M3) { p.vb = strides_v[0]; p.vh = strides_v[1]; p.vs = strides_v[2]; }
+  else { p.vb = p.vh = p.vs = 0; }
+  p.ob = strides_o[0]; p.oh = strides_o[1]; p.os = strides_o[2];
+  p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Sq = Sq; p.Sk = Sk;
+  p.nQ = (Sq + LBFA_BLKQ - 1) / LBFA_BLKQ;
+  p.nK = (Sk + LBFA_BLKK - 1) / LBFA_BLKK;
+  p.group = Hq / Hkv;
+  if ((int64_t)B * Hq * p.nQ > 0x7fffffffLL) return fail(LBFA_EINVAL, "lbfa_attn_fwd: grid too large");
+  g_err[0] = 0;
+  return check_hip(lbfa::launch_attn_fwd(p, D, v_dtype, o_dtype, is_causal ? 1 : 0, (hipStream_t)stream), "lbfa_attn_fwd launch");
+}
+
+}  // extern "C"

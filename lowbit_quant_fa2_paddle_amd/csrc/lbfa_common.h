@@ -1,0 +1,95 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of liblowbit_fa_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lowbit_fa.h"
+
+namespace lbfa {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+
+// ---- storage-dtype conversions (raw 16-bit patterns <-> fp32) -------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  // round-to-nearest-even; NaN stays NaN (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float f16_bits_to_f32(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+__device__ __forceinline__ unsigned short f32_to_f16_bits(float f) {
+  _Float16 h = (_Float16)f;
+  return __builtin_bit_cast(unsigned short, h);
+}
+template <int DT>
+__device__ __forceinline__ float load_cvt(unsigned short b) {
+  if constexpr (DT == LBFA_F16) return f16_bits_to_f32(b);
+  else return bf16_bits_to_f32(b);
+}
+template <int DT>
+__device__ __forceinline__ unsigned short store_cvt(float f) {
+  if constexpr (DT == LBFA_F16) return f32_to_f16_bits(f);
+  else return f32_to_bf16_bits(f);
+}
+
+// ---- wave-level reductions ------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// XCD-aware bijective remap of a 1-D grid: hardware deals consecutive workgroup ids round-robin over
+// the 8 XCDs, so ids {x, x+8, x+16, ...} share one L2.  Give each such residue class a CONTIGUOUS
+// chunk of the logical work list, so that neighbours in the work list (same (batch, kv-head): same
+// K/V panel) hit one XCD's L2.  Speed only - any placement is correct.
+__device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned n) {
+  const unsigned xcd = id & 7u, j = id >> 3;
+  const unsigned q = n >> 3, r = n & 7u;
+  const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + j;
+}
+
+// ---- launch parameter blocks shared by the kernels and the C-ABI layer ---------------------------
+struct QuantParams {
+  const unsigned short* x;
+  const unsigned short* mean;        // [B, H/mean_group, D] or null
+  int8_t* out;
+  float* scale;                      // [B,H,nblk]
+  const unsigned short* rowdot_vec;  // [B, H/rowdot_group, D] or null
+  float* rowdot_out;                 // [B,H,S]
+  int64_t xb, xh, xs, ob, oh, os;
+  float sm_scale, qmax;
+  int B, H, S, nblk, mean_group, rowdot_group;
+};
+
+struct AttnParams {
+  const int8_t* q;
+  const int8_t* k;
+  const void* v;
+  void* o;
+  float* lse;
+  const float* q_scale;
+  const float* k_scale;
+  const float* v_scale;
+  int64_t qb, qh, qs, kb, kh, ks, vb, vh, vs, ob, oh, os;
+  int B, Hq, Hkv, Sq, Sk, nQ, nK, group;
+};
+
+}  // namespace lbfa

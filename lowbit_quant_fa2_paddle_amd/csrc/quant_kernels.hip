@@ -1,0 +1,325 @@
+// Quantisation pre-passes for the low-bit attention path (gfx950).
+//   mean_partial / mean_finalize : km = mean_S(K)                         (src/core.py:292-293)
+//   quant_per_block              : K - km, * sm_scale, per-block amax, int8 (src/triton/quant_per_block.py:132-178)
+//   quant_v_fp8                  : per-channel e4m3 V                      (csrc/fused/fused.cu:317-428)
+// All of these are pure HBM streaming: 16-byte loads per lane, values kept in registers between the
+// amax pass and the encode pass so every input byte is read exactly once.
+// Built with -ffp-contract=off and correctly rounded fp32 division: the int8 codes and the scales are
+// bit-exact against the CPU oracle.
+#include "lbfa_common.h"
+
+namespace lbfa {
+
+// ---------------------------------------------------------------------------------------------------
+// mean over the sequence
+// ---------------------------------------------------------------------------------------------------
+struct MeanParams {
+  const unsigned short* x;
+  float* partial;   // [B,H,nsplit,D]
+  void* out;        // [B,H,D] storage dtype
+  int64_t sb, sh, ss;
+  int B, H, S, D, rows_per_split, nsplit;
+};
+
+template <int DT, int D>
+__global__ __launch_bounds__(256) void mean_partial_kernel(MeanParams p) {
+  constexpr int CPR = D / 8;        // 16-byte chunks per row
+  constexpr int RL = 256 / CPR;     // rows in flight per pass
+  __shared__ float red[RL][D + 1];
+  const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int t = threadIdx.x, c = t % CPR, rl = t / CPR;
+  const unsigned short* base = p.x + (int64_t)b * p.sb + (int64_t)h * p.sh + c * 8;
+  const int r0 = split * p.rows_per_split;
+  const int r1 = min(r0 + p.rows_per_split, p.S);
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int r = r0 + rl; r < r1; r += RL) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(base + (int64_t)r * p.ss);
+    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[2 * i] += load_cvt<DT>((unsigned short)(w[i] & 0xffffu));
+      acc[2 * i + 1] += load_cvt<DT>((unsigned short)(w[i] >> 16));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[rl][c * 8 + i] = acc[i];
+  __syncthreads();
+  if (t < D) {
+    float s = 0.f;
+#pragma unroll 4
+    for (int r = 0; r < RL; ++r) s += red[r][t];
+    p.partial[(((int64_t)b * p.H + h) * p.nsplit + split) * D + t] = s;
+  }
+}
+
+template <int DT>
+__global__ void mean_finalize_kernel(MeanParams p) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*H*D
+  const int64_t n = (int64_t)p.B * p.H * p.D;
+  if (idx >= n) return;
+  const int d = (int)(idx % p.D);
+  const int64_t bh = idx / p.D;
+  const float* src = p.partial + bh * p.nsplit * p.D + d;
+  float s = 0.f;
+  for (int i = 0; i < p.nsplit; ++i) s += src[(int64_t)i * p.D];
+  reinterpret_cast<unsigned short*>(p.out)[idx] = store_cvt<DT>(s / (float)p.S);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-block int8 / int4-range quantiser
+// ---------------------------------------------------------------------------------------------------
+
+template <int DT, int D, int BLK>
+__global__ __launch_bounds__(256) void quant_per_block_kernel(QuantParams p) {
+  constexpr int CPR = D / 8;
+  constexpr int RPP = 256 / CPR;  // rows per pass
+  constexpr int NP = BLK / RPP;   // passes
+  __shared__ float wmax[4];
+  const int blk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int t = threadIdx.x, c = t % CPR, rl = t / CPR;
+  const unsigned short* xbase = p.x + (int64_t)b * p.xb + (int64_t)h * p.xh + c * 8;
+  int8_t* obase = p.out + (int64_t)b * p.ob + (int64_t)h * p.oh + c * 8;
+
+  float mean[8];
+  const bool has_mean = p.mean != nullptr;
+  if (has_mean) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(p.mean + ((int64_t)b * (p.H / p.mean_group) + h / p.mean_group) * D + c * 8);
+    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      mean[2 * i] = load_cvt<DT>((unsigned short)(w[i] & 0xffffu));
+      mean[2 * i + 1] = load_cvt<DT>((unsigned short)(w[i] >> 16));
+    }
+  }
+  float vec[8];
+  const bool has_dot = p.rowdot_vec != nullptr;
+  if (has_dot) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(p.rowdot_vec + ((int64_t)b * (p.H / p.rowdot_group) + h / p.rowdot_group) * D + c * 8);
+    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      vec[2 * i] = load_cvt<DT>((unsigned short)(w[i] & 0xffffu));
+      vec[2 * i + 1] = load_cvt<DT>((unsigned short)(w[i] >> 16));
+    }
+  }
+
+  float xs[NP][8];
+  float amax = 0.f;
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    const int row = blk * BLK + ps * RPP + rl;
+    uint4 raw = make_uint4(0, 0, 0, 0);  // masked rows load as 0 (quant_per_block.py:170)
+    if (row < p.S) raw = *reinterpret_cast<const uint4*>(xbase + (int64_t)row * p.xs);
+    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = load_cvt<DT>((unsigned short)((i & 1) ? (w[i >> 1] >> 16) : (w[i >> 1] & 0xffffu)));
+      if (has_dot) dot += v * vec[i];
+      // `k - km` is an elementwise op in the storage dtype (quant_per_block.py:186-187): the fp32
+      // difference is rounded to that dtype, as the CPU oracle (and torch/paddle CPU) does.
+      // (rows past the end stay 0: the reference subtracts on the real tensor, then loads masked rows as 0)
+      if (has_mean && row < p.S) v = load_cvt<DT>(store_cvt<DT>(v - mean[i]));
+      v = v * p.sm_scale;
+      xs[ps][i] = v;
+      amax = fmaxf(amax, fabsf(v));
+    }
+    if (has_dot) {
+#pragma unroll
+      for (int o = CPR / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+      if (c == 0 && row < p.S)
+        p.rowdot_out[((int64_t)b * p.H + h) * p.S + row] = load_cvt<DT>(store_cvt<DT>(dot));
+    }
+  }
+  amax = wave_max(amax);
+  if ((t & 63) == 0) wmax[t >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  const float scale = fmaxf(amax, 1e-7f) / p.qmax;
+  if (t == 0) p.scale[((int64_t)b * p.H + h) * p.nblk + blk] = scale;
+
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    const int row = blk * BLK + ps * RPP + rl;
+    unsigned w[2] = {0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float y = xs[ps][i] / scale;
+      y = y + (y >= 0.f ? 0.5f : -0.5f);  // round half away from zero (:174-176)
+      const int q = (int)y;               // trunc
+      w[i >> 2] |= ((unsigned)q & 0xffu) << (8 * (i & 3));
+    }
+    if (row < p.S) *reinterpret_cast<uint2*>(obase + (int64_t)row * p.os) = make_uint2(w[0], w[1]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-channel e4m3 quantiser for V
+// ---------------------------------------------------------------------------------------------------
+struct VFp8Params {
+  const unsigned short* v;
+  uint8_t* out;        // [B,H,ntile,D,64]
+  float* v_scale;      // [B,H,D]
+  unsigned* amax_bits; // [B,H,D] scratch at the tail of the v_fp8 allocation; zeroed before the launch
+  int64_t vb, vh, vs;
+  int B, H, S, ntile, rows_per_split;
+};
+
+// key permutation inside a 64-key tile: position -> key.  The MFMA B-operand built from the S^T
+// accumulator holds, for k-step ks (16 keys) and lane half hh, keys 16ks + 8(j>>2) + 4hh + (j&3),
+// j = 0..7 (cdna_hip_programming.md "An accumulator tile as the next MFMA's operand").  Storing V^T with
+// the keys of (ks, hh) contiguous lets the A operand be fetched with one 8-byte LDS read.
+__device__ __forceinline__ int vfp8_pos_of_key(int key) {
+  const int ks = key >> 4, w = key & 15;
+  const int j = ((w >> 3) << 2) | (w & 3), hh = (w >> 2) & 1;
+  return ks * 16 + hh * 8 + j;
+}
+
+template <int DT, int D>
+__global__ __launch_bounds__(256) void v_amax_kernel(VFp8Params p) {
+  // channel amax over the tokens of one split (fused.cu:391-394); max is order-independent, so the
+  // cross-workgroup combine is an integer atomicMax on the (non-negative) fp32 bit patterns.
+  constexpr int CPR = D / 8;
+  constexpr int RL = 256 / CPR;
+  __shared__ float red[RL][D + 1];
+  const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int t = threadIdx.x, c = t % CPR, rl = t / CPR;
+  const unsigned short* base = p.v + (int64_t)b * p.vb + (int64_t)h * p.vh + c * 8;
+  const int r0 = split * p.rows_per_split, r1 = min(r0 + p.rows_per_split, p.S);
+  float am[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) am[i] = 0.f;
+  for (int r = r0 + rl; r < r1; r += RL) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(base + (int64_t)r * p.vs);
+    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      am[2 * i] = fmaxf(am[2 * i], fabsf(load_cvt<DT>((unsigned short)(w[i] & 0xffffu))));
+      am[2 * i + 1] = fmaxf(am[2 * i + 1], fabsf(load_cvt<DT>((unsigned short)(w[i] >> 16))));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[rl][c * 8 + i] = am[i];
+  __syncthreads();
+  if (t < D) {
+    float s = 0.f;
+    for (int r = 0; r < RL; ++r) s = fmaxf(s, red[r][t]);
+    atomicMax(p.amax_bits + ((int64_t)b * p.H + h) * D + t, __float_as_uint(s));
+  }
+}
+
+template <int DT, int D>
+__global__ __launch_bounds__(256) void v_encode_kernel(VFp8Params p) {
+  // one workgroup per (tile, h, b): 64 keys x D channels -> [D][64] bytes, keys permuted
+  __shared__ __attribute__((aligned(16))) uint8_t tile[D][64 + 16];
+  constexpr int CPR = D / 8;
+  constexpr int RPP = 256 / CPR;
+  const int tl = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int t = threadIdx.x, c = t % CPR, rl = t / CPR;
+  const unsigned short* base = p.v + (int64_t)b * p.vb + (int64_t)h * p.vh + c * 8;
+  float inv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float amax = fmaxf(__uint_as_float(p.amax_bits[((int64_t)b * p.H + h) * D + c * 8 + i]), 1e-7f);
+    inv[i] = 448.0f / amax;  // recp_scale (fused.cu:400)
+    if (tl == 0 && rl == 0) p.v_scale[((int64_t)b * p.H + h) * D + c * 8 + i] = amax / 448.0f;  // fused.cu:394
+  }
+#pragma unroll
+  for (int ps = 0; ps < 64 / RPP; ++ps) {
+    const int key = ps * RPP + rl;
+    const int row = tl * 64 + key;
+    uint4 raw = make_uint4(0, 0, 0, 0);
+    if (row < p.S) raw = *reinterpret_cast<const uint4*>(base + (int64_t)row * p.vs);
+    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+    const int pos = vfp8_pos_of_key(key);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float v = load_cvt<DT>((unsigned short)((i & 1) ? (w[i >> 1] >> 16) : (w[i >> 1] & 0xffffu))) * inv[i];
+      // v_cvt_pk_fp8_f32: OCP e4m3fn on gfx950, RNE, saturating
+      const unsigned pk = __builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0u, false);
+      // 8-byte slot XOR-swizzled by the channel so the attention kernel's ds_read_b64 of 32 channels
+      // x one slot is bank-conflict-free (row stride 64 B -> 4 rows per 256-B bank window).
+      const int d = c * 8 + i;
+      tile[d][pos ^ (((d >> 2) & 7) << 3)] = (uint8_t)(pk & 0xffu);
+    }
+  }
+  __syncthreads();
+  uint8_t* dst = p.out + ((((int64_t)b * p.H + h) * p.ntile + tl) * D) * 64;
+  // D*64 bytes, 16 B per thread per pass
+  for (int idx = t; idx < D * 4; idx += 256) {
+    const int d = idx >> 2, q = idx & 3;
+    *reinterpret_cast<uint4*>(dst + d * 64 + q * 16) = *reinterpret_cast<const uint4*>(&tile[d][q * 16]);
+  }
+}
+
+}  // namespace lbfa
+
+// ---------------------------------------------------------------------------------------------------
+// host-side launchers (called from lbfa_api.hip)
+// ---------------------------------------------------------------------------------------------------
+namespace lbfa {
+
+int mean_rows_per_split(int S) { return S <= 16384 ? 256 : 1024; }
+
+hipError_t launch_mean_seq(const void* x, int dtype, void* out, void* ws, int B, int H, int S, int D,
+                           const int64_t* st, hipStream_t stream) {
+  MeanParams p;
+  p.x = (const unsigned short*)x;
+  p.partial = (float*)ws;
+  p.out = out;
+  p.sb = st[0]; p.sh = st[1]; p.ss = st[2];
+  p.B = B; p.H = H; p.S = S; p.D = D;
+  p.rows_per_split = mean_rows_per_split(S);
+  p.nsplit = (S + p.rows_per_split - 1) / p.rows_per_split;
+  dim3 grid(p.nsplit, H, B);
+#define LBFA_MEAN(DT, DD) hipLaunchKernelGGL((mean_partial_kernel<DT, DD>), grid, dim3(256), 0, stream, p)
+  if (dtype == LBFA_F16) { if (D == 64) LBFA_MEAN(LBFA_F16, 64); else LBFA_MEAN(LBFA_F16, 128); }
+  else { if (D == 64) LBFA_MEAN(LBFA_BF16, 64); else LBFA_MEAN(LBFA_BF16, 128); }
+#undef LBFA_MEAN
+  const int64_t n = (int64_t)B * H * D;
+  dim3 g2((unsigned)((n + 255) / 256));
+  if (dtype == LBFA_F16) hipLaunchKernelGGL((mean_finalize_kernel<LBFA_F16>), g2, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((mean_finalize_kernel<LBFA_BF16>), g2, dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_quant_per_block(const QuantParams& p, int dtype, int D, int blk, hipStream_t stream) {
+  dim3 grid(p.nblk, p.H, p.B);
+#define LBFA_Q(DT, DD, BB) hipLaunchKernelGGL((quant_per_block_kernel<DT, DD, BB>), grid, dim3(256), 0, stream, p)
+#define LBFA_Q2(DT)                                         \
+  if (D == 64 && blk == 128) LBFA_Q(DT, 64, 128);           \
+  else if (D == 64 && blk == 64) LBFA_Q(DT, 64, 64);        \
+  else if (D == 128 && blk == 128) LBFA_Q(DT, 128, 128);    \
+  else LBFA_Q(DT, 128, 64);
+  if (dtype == LBFA_F16) { LBFA_Q2(LBFA_F16) } else { LBFA_Q2(LBFA_BF16) }
+#undef LBFA_Q2
+#undef LBFA_Q
+  return hipGetLastError();
+}
+
+size_t v_fp8_payload_bytes(int B, int H, int S, int D) { return (size_t)B * H * ((S + 63) / 64) * D * 64; }
+
+hipError_t launch_quant_v_fp8(const void* v, int dtype, uint8_t* out, float* v_scale, int B, int H, int S, int D,
+                              const int64_t* st, hipStream_t stream) {
+  VFp8Params p;
+  p.v = (const unsigned short*)v; p.out = out; p.v_scale = v_scale;
+  p.amax_bits = reinterpret_cast<unsigned*>(out + v_fp8_payload_bytes(B, H, S, D));
+  p.vb = st[0]; p.vh = st[1]; p.vs = st[2];
+  p.B = B; p.H = H; p.S = S; p.ntile = (S + 63) / 64;
+  p.rows_per_split = 512;
+  const int nsplit = (S + p.rows_per_split - 1) / p.rows_per_split;
+  hipError_t e = hipMemsetAsync(p.amax_bits, 0, (size_t)B * H * D * sizeof(unsigned), stream);
+  if (e != hipSuccess) return e;
+  dim3 g1(nsplit, H, B), g2(p.ntile, H, B);
+#define LBFA_V(DT, DD)                                                               \
+  hipLaunchKernelGGL((v_amax_kernel<DT, DD>), g1, dim3(256), 0, stream, p);          \
+  hipLaunchKernelGGL((v_encode_kernel<DT, DD>), g2, dim3(256), 0, stream, p)
+  if (dtype == LBFA_F16) { if (D == 64) { LBFA_V(LBFA_F16, 64); } else { LBFA_V(LBFA_F16, 128); } }
+  else { if (D == 64) { LBFA_V(LBFA_BF16, 64); } else { LBFA_V(LBFA_BF16, 128); } }
+#undef LBFA_V
+  return hipGetLastError();
+}
+
+}  // namespace lbfa

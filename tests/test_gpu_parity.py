@@ -1,0 +1,279 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C ABI via the Python
+front end, against the CPU oracle and the committed golden vectors of the reference's Triton kernels.
+
+Bars:
+  * quantiser codes and scales: bit-exact;
+  * km (mean over the sequence): within one ulp of the storage dtype (summation order);
+  * attention O: |dO| <= 2e-3 + 2e-3*|O| vs the golden reference output / oracle (fp16 out; the kernel
+    accumulates PV in fp32 where the reference rounds each 64-key tile product to fp16, and v_exp_f32
+    is a ~1-ulp approximation); bf16 out adds one bf16 ulp (2^-7 relative);
+  * LSE: <= 1e-3 abs;
+  * sanity vs fp32 SDPA: MSE <= 1e-5 on N(0,1) inputs (int8), <= 1e-4 (fp8 PV, int4).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+TDT = {"fp16": torch.float16, "bf16": torch.bfloat16}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from lowbit_quant_fa2_paddle_amd import _lib
+    _lib.load()  # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def _t(a, dtype, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(TDT[dtype]).to(dev)
+
+
+def _np(t):
+    return t.detach().float().cpu().numpy()
+
+
+def _canon(a, layout):
+    return a if layout == "HND" else np.transpose(a, (0, 2, 1, 3))
+
+
+def _o_close(o, ref, dtype, atol=2e-3, rtol=2e-3):
+    if dtype == "bf16":
+        rtol = rtol + 2.0 ** -7
+    err = np.abs(o - ref)
+    bad = err > atol + rtol * np.abs(ref)
+    assert not bad.any(), f"max err {err.max():.3e} at {np.argwhere(bad)[:3].tolist()} ({bad.sum()} elements)"
+
+
+# ------------------------------------------------------------------------------------------------------
+# quantiser
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout", ["HND", "NHD"])
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("S,D", [(256, 64), (300, 128), (64, 64), (1, 64), (129, 128)])
+def test_mean_and_quant_bit_exact(oracle, dev, layout, dtype, S, D):
+    from lowbit_quant_fa2_paddle_amd import quant_per_block as qpb
+    B, H = 2, 3
+    q, k, v = oracle.make_inputs(B, H, S, D, seed=11, layout=layout, dtype=dtype, k_bias=0.3)
+    tq, tk = _t(q, dtype, dev), _t(k, dtype, dev)
+    km = qpb.mean_seq(tk, layout)
+    km_np = _np(km).reshape(B, H, 1, D)
+    km_ref = oracle.mean_seq(_canon(k, layout), dtype)
+    ulp = (2.0 ** -10 if dtype == "fp16" else 2.0 ** -7) * np.maximum(np.abs(km_ref), 2.0 ** -14)
+    assert np.all(np.abs(km_np - km_ref) <= ulp), np.abs(km_np - km_ref).max()
+    sm_scale = 1.0 / D ** 0.5
+    q8, qs, k8, ks = qpb.per_block_int8(tq, tk, km=km, sm_scale=sm_scale, tensor_layout=layout)
+    # oracle fed with the km the device produced: everything downstream is bit-exact
+    rq8, rqs, rk8, rks = oracle.per_block_int8(_canon(q, layout), _canon(k, layout), km_np, sm_scale, dtype, amax_floor=1e-7)
+    assert np.array_equal(_canon(q8.cpu().numpy(), layout), rq8)
+    assert np.array_equal(_canon(k8.cpu().numpy(), layout), rk8)
+    assert np.array_equal(qs.cpu().numpy().view(np.uint32), rqs.view(np.uint32))
+    assert np.array_equal(ks.cpu().numpy().view(np.uint32), rks.view(np.uint32))
+
+
+@pytest.mark.parametrize("fn,qm,km_", [("per_block_int4_unpack", 7, 7), ("per_block_q_int8_k_int4", 127, 7)])
+def test_int4_range_quant_bit_exact(oracle, dev, fn, qm, km_):
+    from lowbit_quant_fa2_paddle_amd import quant_per_block as qpb
+    q, k, v = oracle.make_inputs(1, 2, 256, 64, seed=5)
+    tq, tk = _t(q, "fp16", dev), _t(k, "fp16", dev)
+    q8, qs, k8, ks = getattr(qpb, fn)(tq, tk, sm_scale=0.125)
+    rq8, rqs, rk8, rks = oracle.per_block_int8(q, k, None, 0.125, "fp16", q_qmax=qm, k_qmax=km_, amax_floor=1e-7)
+    assert np.array_equal(q8.cpu().numpy(), rq8) and np.array_equal(k8.cpu().numpy(), rk8)
+    assert np.array_equal(qs.cpu().numpy().view(np.uint32), rqs.view(np.uint32))
+    assert np.array_equal(ks.cpu().numpy().view(np.uint32), rks.view(np.uint32))
+    assert np.abs(k8.cpu().numpy()).max() <= 7
+
+
+def test_quant_degenerate_blocks(oracle, dev):
+    """All-zero block: the reference Triton kernel yields NaN (no epsilon); the HIP path floors amax at 1e-7
+    like the CUDA quantiser (fused.cu:147) and emits zeros.  A block holding one huge value saturates at qmax."""
+    from lowbit_quant_fa2_paddle_amd import quant_per_block as qpb
+    x = torch.zeros(1, 1, 256, 64, dtype=torch.float16, device=dev)
+    x[0, 0, 130, 5] = 60000.0
+    x[0, 0, 131, 6] = -60000.0
+    c, s = qpb.quantize(x, sm_scale=1.0, qmax=127, blk=128)
+    c, s = c.cpu().numpy(), s.cpu().numpy()
+    assert np.all(c[0, 0, :128] == 0) and s[0, 0, 0] == np.float32(1e-7) / np.float32(127)
+    assert c[0, 0, 130, 5] == 127 and c[0, 0, 131, 6] == -127 and np.isfinite(s).all()
+
+
+# ------------------------------------------------------------------------------------------------------
+# attention kernel on the reference's own codes/scales (golden fixtures)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_names())
+def test_attention_kernel_vs_reference_golden(oracle, dev, name):
+    """Feed the golden int8 codes + scales (made by the reference's quantiser kernels) to lbfa_attn_fwd and
+    compare with the reference attention kernel's O and LSE."""
+    from lowbit_quant_fa2_paddle_amd import attn_qk_int8_per_block as attn
+    p, g = load_golden(name)
+    q, k, v = oracle.make_inputs(p["B"], p["H"], p["S"], p["D"], seed=p["seed"], layout=p["layout"], dtype=p["dtype"],
+                                 Hkv=p["Hkv"], Sk=p["Sk"], k_bias=p["k_bias"])
+    Dp = g["q_i8"].shape[-1]
+    if Dp != p["D"]:
+        v = np.pad(v, [(0, 0)] * 3 + [(0, Dp - p["D"])])
+    q8 = torch.from_numpy(g["q_i8"]).to(dev)
+    k8 = torch.from_numpy(g["k_i8"]).to(dev)
+    qs = torch.from_numpy(g["q_scale"]).to(dev)
+    ks = torch.from_numpy(g["k_scale"]).to(dev)
+    tv = _t(v, p["dtype"], dev)
+    o, lse = attn.forward(q8, k8, tv, qs, ks, tensor_layout=p["layout"], output_dtype=TDT[p["dtype"]],
+                          return_lse=True, is_causal=p["causal"])
+    _o_close(_np(o)[..., :p["D"]], g["o"], p["dtype"])
+    assert np.abs(lse.cpu().numpy() - g["lse2"]).max() <= 1e-3
+
+
+# ------------------------------------------------------------------------------------------------------
+# full operator vs oracle
+# ------------------------------------------------------------------------------------------------------
+CASES = [
+    # B, H, Hkv, Sq, Sk, D, layout, causal, dtype
+    (1, 2, 2, 256, 256, 64, "HND", False, "fp16"),       # BASELINE config 1
+    (1, 2, 2, 256, 256, 64, "HND", True, "fp16"),
+    (2, 4, 2, 384, 384, 128, "NHD", True, "fp16"),       # GQA + NHD + causal (config 3 shape family)
+    (1, 2, 1, 200, 333, 64, "HND", False, "fp16"),       # ragged Sq / Sk
+    (1, 2, 2, 333, 333, 128, "NHD", True, "fp16"),       # ragged causal
+    (1, 3, 3, 1, 77, 64, "HND", False, "fp16"),          # single query row
+    (1, 2, 2, 512, 512, 80, "HND", False, "fp16"),       # head-dim pad path 80 -> 128
+    (1, 2, 2, 256, 256, 32, "NHD", True, "bf16"),        # head-dim pad 32 -> 64, bf16 in/out
+    (1, 2, 2, 640, 640, 128, "HND", False, "bf16"),
+]
+
+
+@pytest.mark.parametrize("B,H,Hkv,Sq,Sk,D,layout,causal,dtype", CASES)
+def test_operator_int8_fp16_vs_oracle(oracle, dev, B, H, Hkv, Sq, Sk, D, layout, causal, dtype):
+    import lowbit_quant_fa2_paddle_amd as lb
+    q, k, v = oracle.make_inputs(B, H, Sq, D, seed=21, layout=layout, dtype=dtype, Hkv=Hkv, Sk=Sk, k_bias=0.5)
+    tq, tk, tv = (_t(a, dtype, dev) for a in (q, k, v))
+    o, lse = lb.lowbit_fa_qk_int8_pv_fp16_triton(tq, tk, tv, tensor_layout=layout, is_causal=causal, return_lse=True)
+    assert o.shape == tq.shape and o.dtype == tq.dtype and tuple(lse.shape) == (B, H, Sq)
+    o_ref, lse_ref = oracle.lowbit_fa_forward(q, k, v, dtype=dtype, tensor_layout=layout, is_causal=causal,
+                                              return_lse=True, tail="neg_inf", amax_floor=1e-7)
+    _o_close(_np(o), o_ref, dtype)
+    # lse_correction (q . km) is rounded to the storage dtype by the reference (src/core.py:294-304): allow one
+    # ulp of that rounding on top of the 1e-3 kernel tolerance
+    corr_ulp = (2.0 ** -10 if dtype == "fp16" else 2.0 ** -7) * np.abs(lse_ref).max()
+    assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 1e-3 + corr_ulp
+    # sanity vs exact attention
+    ref = oracle.sdpa_naive(_canon(q, layout).astype(np.float64), _canon(k, layout).astype(np.float64),
+                            _canon(v, layout).astype(np.float64), is_causal=causal)
+    mse = float(np.mean((_canon(_np(o), layout) - ref) ** 2))
+    assert mse <= (1e-5 if dtype == "fp16" else 3e-5), mse
+
+
+@pytest.mark.parametrize("smooth_k", [True, False])
+@pytest.mark.parametrize("return_lse", [True, False])
+def test_operator_flags(oracle, dev, smooth_k, return_lse):
+    import lowbit_quant_fa2_paddle_amd as lb
+    q, k, v = oracle.make_inputs(1, 2, 256, 64, seed=3, k_bias=1.0)
+    tq, tk, tv = (_t(a, "fp16", dev) for a in (q, k, v))
+    out = lb.sageattn_qk_int8_pv_fp16_cuda(tq, tk, tv, smooth_k=smooth_k, return_lse=return_lse, sm_scale=0.1,
+                                           pv_accum_dtype="fp16+fp32", qk_quant_gran="per_warp")
+    ref = oracle.lowbit_fa_forward(q, k, v, smooth_k=smooth_k, return_lse=return_lse, sm_scale=0.1, amax_floor=1e-7)
+    if return_lse:
+        _o_close(_np(out[0]), ref[0], "fp16")
+        assert np.abs(out[1].cpu().numpy() - ref[1]).max() <= 2e-3
+    else:
+        _o_close(_np(out), ref, "fp16")
+
+
+@pytest.mark.parametrize("q_bits", [4, 8])
+@pytest.mark.parametrize("causal", [False, True])
+def test_operator_int4(oracle, dev, q_bits, causal):
+    import lowbit_quant_fa2_paddle_amd as lb
+    q, k, v = oracle.make_inputs(1, 2, 512, 64, seed=9)
+    tq, tk, tv = (_t(a, "fp16", dev) for a in (q, k, v))
+    o = lb.lowbit_fa_qk_int4_pv_fp16_triton(tq, tk, tv, is_causal=causal, q_bits=q_bits)
+    o_ref = oracle.lowbit_fa_forward(q, k, v, is_causal=causal, q_qmax=7 if q_bits == 4 else 127, k_qmax=7, amax_floor=1e-7)
+    _o_close(_np(o), o_ref, "fp16")
+    ref = oracle.sdpa_naive(q.astype(np.float64), k.astype(np.float64), v.astype(np.float64), is_causal=causal)
+    assert float(np.mean((_np(o) - ref) ** 2)) <= 5e-3  # 4-bit codes: coarse by construction
+
+
+@pytest.mark.parametrize("B,H,Hkv,S,D,layout,causal,dtype", [
+    (1, 2, 2, 256, 64, "HND", False, "fp16"),
+    (2, 4, 2, 384, 128, "NHD", True, "fp16"),
+    (1, 2, 2, 333, 128, "HND", False, "bf16"),
+    (1, 2, 2, 200, 64, "NHD", True, "fp16"),
+])
+def test_operator_int8_fp8_vs_oracle(oracle, dev, B, H, Hkv, S, D, layout, causal, dtype):
+    """fp8-PV: the oracle restates CUDA code that cannot run here and the reference holds no fixture -
+    parity unpinned; checked against that restatement (loosely: e4m3 P has 3 mantissa bits, and exp2
+    rounding differences flip fp8 codes) and against fp32 SDPA."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    q, k, v = oracle.make_inputs(B, H, S, D, seed=31, layout=layout, dtype=dtype, Hkv=Hkv, k_bias=0.25)
+    tq, tk, tv = (_t(a, dtype, dev) for a in (q, k, v))
+    o, lse = lb.lowbit_fa_qk_int8_pv_fp8_cuda(tq, tk, tv, tensor_layout=layout, is_causal=causal, return_lse=True)
+    o_ref, lse_ref = oracle.lowbit_fa_forward(q, k, v, dtype=dtype, tensor_layout=layout, is_causal=causal,
+                                              return_lse=True, pv="fp8", amax_floor=1e-7)
+    _o_close(_np(o), o_ref, dtype, atol=1e-2, rtol=2e-2)
+    assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 2e-3 + 2.0 ** -9 * np.abs(lse_ref).max()
+    ref = oracle.sdpa_naive(_canon(q, layout).astype(np.float64), _canon(k, layout).astype(np.float64),
+                            _canon(v, layout).astype(np.float64), is_causal=causal)
+    mse = float(np.mean((_canon(_np(o), layout) - ref) ** 2))
+    assert mse <= 1e-4, mse
+
+
+def test_v_fp8_quant_exact(oracle, dev):
+    """per_channel_fp8: scales bit-exact, e4m3 codes equal to the numpy e4m3fn RNE-saturating encoder."""
+    from lowbit_quant_fa2_paddle_amd import quant
+    B, H, S, D = 1, 2, 200, 64
+    _, _, v = oracle.make_inputs(B, H, S, D, seed=13)
+    tv = _t(v, "fp16", dev)
+    v8, vs, vm = quant.per_channel_fp8(tv)
+    assert vm is None
+    ref8, ref_s = oracle.per_channel_fp8(v)
+    assert np.array_equal(vs.cpu().numpy().view(np.uint32), ref_s.view(np.uint32))
+    raw = v8.buf.cpu().numpy()
+    ntile = (S + 63) // 64
+    tiles = raw[: B * H * ntile * D * 64].reshape(B, H, ntile, D, 64)
+    codes = oracle.e4m3fn_encode(ref8)  # [B,H,S,D]
+    got = np.zeros((B, H, ntile * 64, D), np.uint8)
+    for key in range(64):
+        ks_, w = key >> 4, key & 15
+        pos = ks_ * 16 + ((w >> 2) & 1) * 8 + (((w >> 3) << 2) | (w & 3))
+        for d in range(D):
+            got[:, :, key::64, d][:, :, :ntile] = tiles[:, :, :, d, pos ^ (((d >> 2) & 7) << 3)]
+    assert np.array_equal(got[:, :, :S], codes)
+    assert np.all(got[:, :, S:] == 0)
+
+
+def test_varlen_and_dispatchers(oracle, dev):
+    import lowbit_quant_fa2_paddle_amd as lb
+    H, D = 2, 64
+    lens = [100, 256, 37]
+    rng = np.random.default_rng(0)
+    q = oracle.to_storage(rng.standard_normal((sum(lens), H, D), dtype=np.float32), "fp16")
+    k = oracle.to_storage(rng.standard_normal((sum(lens), H, D), dtype=np.float32), "fp16")
+    v = oracle.to_storage(rng.standard_normal((sum(lens), H, D), dtype=np.float32), "fp16")
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    tq, tk, tv = (_t(a, "fp16", dev) for a in (q, k, v))
+    tcu = torch.from_numpy(cu).to(dev)
+    o = lb.lowbit_fa_varlen(tq, tk, tv, tcu, tcu, max(lens), max(lens), is_causal=True)
+    assert tuple(o.shape) == (sum(lens), H, D)
+    for i, n in enumerate(lens):
+        sl = slice(cu[i], cu[i + 1])
+        ref = oracle.lowbit_fa_forward(q[sl][None], k[sl][None], v[sl][None], tensor_layout="NHD", is_causal=True,
+                                       tail="neg_inf", amax_floor=1e-7)
+        _o_close(_np(o[sl]), ref[0], "fp16")
+    # auto dispatcher and the precision router
+    q4, k4, v4 = oracle.make_inputs(1, 2, 128, 64, seed=1)
+    t4 = [_t(a, "fp16", dev) for a in (q4, k4, v4)]
+    o_a = lb.lowbit_fa_attn(*t4)
+    o_b = lb.lowbit_fa_qk_int8_pv_fp16_triton(*t4)
+    assert torch.equal(o_a, o_b)
+    # precision router (src/core.py:1051-1096): N(0,1) -> max|x|/127 ~ 0.035 < 0.05 -> INT4; x3 -> INT8; x8 -> FP16
+    assert lb.core.select_quantization(*t4) == "INT4"
+    assert torch.equal(lb.lowbit_fa_multi_precision(*t4), lb.lowbit_fa_qk_int4_pv_fp16_triton(*t4))
+    t12 = [t * 3 for t in t4]
+    assert lb.core.select_quantization(*t12) == "INT8"
+    assert torch.equal(lb.lowbit_fa_multi_precision(*t12), lb.lowbit_fa_qk_int8_pv_fp16_triton(*t12))
+    t32 = [t * 8 for t in t4]
+    assert lb.core.select_quantization(*t32) == "FP16"
+    o_fp = lb.lowbit_fa_multi_precision(*t32)
+    ref = oracle.sdpa_naive(*(x.astype(np.float64) * 8 for x in (q4, k4, v4)))
+    # plain fp16 matmul SDPA on x8 inputs: scores ~ +-500 carry fp16 rounding of 0.25 -> loose check
+    assert np.abs(_np(o_fp) - ref).max() <= 0.1 * np.abs(ref).max()

@@ -11,7 +11,8 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "liblowbit_fa_hip.so"
-LIB_PATH = os.path.join(_HERE, LIB_NAME)
+# LBFA_LIB_PATH: development override to A/B kernel builds (same C ABI)
+LIB_PATH = os.environ.get("LBFA_LIB_PATH") or os.path.join(_HERE, LIB_NAME)
 
 LBFA_F16, LBFA_BF16, LBFA_E4M3 = 0, 1, 2
 LBFA_OK, LBFA_EINVAL, LBFA_ELAUNCH = 0, 1, 2

@@ -61,9 +61,21 @@ __device__ __forceinline__ float half_swap_sum(float x) {
 
 constexpr float kFp8Offset = 8.807f;  // csrc/qattn/attn_utils.cuh:30: p = exp2(s - m + 8.807) -> p_max = 448
 
+#ifndef LBFA_MAGIC
+#define LBFA_MAGIC 0
+#endif
+#ifndef LBFA_DOT2
+#define LBFA_DOT2 0
+#endif
+#ifndef LBFA_THR
+#define LBFA_THR 8.0f
+#endif
+
 template <int D, int VT, int OT, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   constexpr bool FP8 = (VT == LBFA_E4M3);
+  // fp8 P is scaled so that its maximum is 448 = e4m3 max (attn_utils.cuh:30): no headroom to defer
+  constexpr float THR = FP8 ? 0.0f : LBFA_THR;
   constexpr int KS = D / 32;                         // int8 k-steps of the score product
   constexpr int DB = D / 32;                         // 32-channel blocks of O^T
   constexpr int KBYTES = 64 * D;                     // K tile
@@ -171,6 +183,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   float m_run = -INFINITY;  // running max (base-2 domain), identical in both halves of a row
   float l_run = 0.f;        // running sum over THIS lane's keys only (halves are added in the epilogue)
 
+#if LBFA_MAGIC
+  // int32 -> fp32 without a convert: accumulate on top of 1.5*2^23 so the accumulator's BITS are the float
+  // 12582912 + s (exact for |s| < 2^22; |s| <= 127*127*128 < 2^21).  The bias is folded into the fma constant.
+  i32x16 cmagic;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) cmagic[i] = 0x4B400000;
+  constexpr float kMagic = 12582912.0f;
+#endif
+
   auto compute_tile = [&](int buf, int j, auto masked_tag) {
     constexpr bool MASKED = decltype(masked_tag)::value;
     const char* ksm = ksm0 + buf * KBYTES;
@@ -180,13 +201,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     i32x16 sacc[2];
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sacc[kb2][i] = 0;
       const int krow = 32 * kb2 + r;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const i32x4 kf = *reinterpret_cast<const i32x4*>(ksm + krow * D + (((2 * s + hh) ^ kx<D>(krow)) << 4));
-        sacc[kb2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], sacc[kb2], 0, 0, 0);
+        if (s == 0) {
+#if LBFA_MAGIC
+          sacc[kb2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], cmagic, 0, 0, 0);
+#else
+          sacc[kb2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], i32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+#endif
+        } else {
+          sacc[kb2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], sacc[kb2], 0, 0, 0);
+        }
       }
     }
     // -- online softmax, base 2; dequant scale folded into the exponent argument
@@ -197,7 +224,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
+#if LBFA_MAGIC
+        float v = __int_as_float(sacc[kb2][i]);
+#else
         float v = (float)sacc[kb2][i];
+#endif
         if constexpr (MASKED) {
           const int key = n0 + 32 * kb2 + (i & 3) + 8 * (i >> 2) + 4 * hh;
           bool dead = key >= p.Sk;
@@ -208,32 +239,51 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         mloc = fmaxf(mloc, v);
       }
     mloc = half_swap_max(mloc);
-    // sc > 0, so max commutes with the scaling; (-inf)*sc stays -inf
-    const float m_new = fmaxf(m_run, mloc * sc);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // m_run = -inf -> 0
-    m_run = m_new;
-    float neg_m = -m_new;
-    if constexpr (FP8) neg_m += kFp8Offset;
+    // sc > 0, so max commutes with the scaling; -inf stays -inf
+#if LBFA_MAGIC
+    const float m_cand = fmaxf(m_run, __builtin_fmaf(mloc, sc, -kMagic * sc));
+#else
+    const float m_cand = fmaxf(m_run, mloc * sc);
+#endif
+    // Deferred rescale: keep the old reference max while no row of the wave grew by more than THR
+    // (P then stays <= 2^THR, exact in fp16/fp32); rescale O and l only when some row did.
+    // First tile: m_run = -inf, so the branch is taken and alpha = 0.
+    if (__any(m_cand > m_run + THR)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);  // m_run = -inf -> 0
+      m_run = m_cand;
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc_o[db][i] *= alpha;
+    }
+#if LBFA_MAGIC
+    float cexp = __builtin_fmaf(-kMagic, sc, -m_run);
+#else
+    float cexp = -m_run;
+#endif
+    if constexpr (FP8) cexp += kFp8Offset;
     float psum = 0.f;
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kb2][i], sc, neg_m));
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kb2][i], sc, cexp));
         x[kb2][i] = pv;
+#if !LBFA_DOT2
         psum += pv;
+#endif
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc_o[db][i] *= alpha;
 
     // -- O^T += V^T P^T : P^T fragments straight from the score accumulators
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int kb2 = ks >> 1, rb = (ks & 1) * 8;
       if constexpr (FP8) {
+#if LBFA_DOT2
+#pragma unroll
+        for (int e = 0; e < 8; ++e) psum += x[kb2][rb + e];
+#endif
         unsigned w0 = 0, w1 = 0;
         w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[kb2][rb + 0], x[kb2][rb + 1], w0, false);
         w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[kb2][rb + 2], x[kb2][rb + 3], w0, true);
@@ -250,6 +300,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         f16x8 pf;
 #pragma unroll
         for (int e = 0; e < 8; ++e) pf[e] = (_Float16)x[kb2][rb + e];
+#if LBFA_DOT2
+        // row sum of the fp16-rounded probabilities, two per instruction (v_dot2_f32_f16, fp32 accumulate)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          psum = __builtin_amdgcn_fdot2(f16x2{pf[2 * e], pf[2 * e + 1]}, f16x2{(_Float16)1.0f, (_Float16)1.0f}, psum, false);
+#endif
         const int vrow = 16 * ks + 4 * hh + ((lane & 15) >> 2);
         const int vcol = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
 #pragma unroll
@@ -263,27 +319,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         }
       }
     }
+    l_run += psum;
   };
 
-  // ---- main loop: one barrier per tile -----------------------------------------------------------------
+  // ---- tile loop: one barrier per tile.  Full (unmasked) tiles first, branch-free; then the at most
+  // three tiles that need masking (causal diagonal block = 2 tiles, ragged last tile).
+  int n_main = n_tiles;
+  if constexpr (CAUSAL) n_main = min(n_tiles, 2 * qt);
+  else if ((p.Sk & 63) != 0) n_main = n_tiles - 1;
   load_tile(0);
   store_tile(0);
   __syncthreads();
-  const bool ragged = (p.Sk & 63) != 0;
-  for (int j = 0; j < n_tiles; ++j) {
+  int j = 0;
+  for (; j < n_main; ++j) {
     const int buf = j & 1;
     if (j + 1 < n_tiles) load_tile(j + 1);
-    const int n0 = j * 64;
-    bool need_mask = ragged && (j == p.nK - 1);
+    compute_tile(buf, j, std::false_type{});
+    if (j + 1 < n_tiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  for (; j < n_tiles; ++j) {
+    const int buf = j & 1;
+    if (j + 1 < n_tiles) load_tile(j + 1);
     bool skip = false;
-    if constexpr (CAUSAL) {
-      skip = n0 > row0 + 31;                        // every key of the tile is above every row of this wave
-      need_mask = need_mask || (n0 + 63 > row0);    // some key above some row
-    }
-    if (!skip) {
-      if (need_mask) compute_tile(buf, j, std::true_type{});
-      else compute_tile(buf, j, std::false_type{});
-    }
+    if constexpr (CAUSAL) skip = j * 64 > row0 + 31;  // every key of the tile is above every row of this wave
+    if (!skip) compute_tile(buf, j, std::true_type{});
     if (j + 1 < n_tiles) store_tile(buf ^ 1);
     __syncthreads();
   }

@@ -1,0 +1,15 @@
+#!/bin/bash
+# usage: tools/build_variant.sh <name> "<extra hipcc flags>"   -> gpurun_variants/lib_<name>.so  (development A/B builds)
+set -e
+cd "$(dirname "$0")/.."
+name=$1; extra=$2
+out=variants/lib_$name.so
+mkdir -p variants /tmp/lbfa_var_$name
+C=lowbit_quant_fa2_paddle_amd/csrc
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt $extra"
+for f in lbfa_api quant_kernels attn_fwd; do
+  /opt/rocm/bin/hipcc $FLAGS -c $C/$f.hip -o /tmp/lbfa_var_$name/$f.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out /tmp/lbfa_var_$name/*.o
+echo built $out

@@ -7,15 +7,21 @@
 //
 //  * one workgroup = 4 waves = one 128-row Q block (= one q_scale), each wave owns 32 query rows;
 //  * K/V stream through LDS in 64-key tiles (= one k_scale each), double-buffered, staged through
-//    registers with 16-byte coalesced loads issued one tile ahead (global loads fly during the MFMAs);
+//    registers with 16-byte buffer loads issued one tile ahead (they fly during the MFMAs).  Buffer
+//    descriptors bound every operand to its valid extent, so ragged tails read as zeros with no
+//    per-lane guards, and the per-tile address update is one scalar add (voffset is loop-invariant);
 //  * the score product is computed TRANSPOSED, S^T = K Q^T with v_mfma_i32_32x32x32_i8, so that a
 //    lane owns ONE query row (column of S^T = lane&31) and 16 keys per 32-key block in registers:
 //    row max / row sum are in-lane reductions plus a single v_permlane32_swap across the two halves;
+//  * the int32 scores never pass through v_cvt_f32_i32 (a half-rate VALU op on gfx950): the MFMA
+//    accumulates on top of 1.5*2^23, whose bit pattern + s IS the float 12582912+s; subtracting the
+//    row maximum (same bias) gives s - smax exactly, and the dequant scale q_scale*k_scale is folded
+//    into the exp2 argument with one v_fma;
 //  * S^T accumulators feed the PV product directly as the B operand of v_mfma_f32_32x32x16_f16
 //    (O^T = V^T P^T): no LDS round trip for P.  V^T fragments come from a row-major V tile in LDS via
 //    ds_read_b64_tr_b16 (hardware transpose);  O^T keeps the query row on the lane, so the online
-//    softmax rescale is a per-lane scalar multiply;
-//  * dequantisation (q_scale*k_scale) is folded into the exp2 argument with one v_fma.
+//    softmax rescale is a per-lane scalar multiply, and it is deferred while no row's max grows by
+//    more than 2^THR (P stays exactly representable).
 //
 // LDS images (bank-conflict-free for the access patterns above):
 //   K tile  [64 keys][D bytes]   16-B chunk c of row r stored at chunk c ^ kx(r)
@@ -26,7 +32,6 @@
 #include "lbfa_common.h"
 
 namespace lbfa {
-
 
 typedef __fp16 hf16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef __attribute__((address_space(3))) hf16x4* lds_hf16x4_ptr;
@@ -59,14 +64,19 @@ __device__ __forceinline__ float half_swap_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-constexpr float kFp8Offset = 8.807f;  // csrc/qattn/attn_utils.cuh:30: p = exp2(s - m + 8.807) -> p_max = 448
+// Raw buffer resource over [base, base+bytes): out-of-range loads return 0 (hardware bounds check).
+// Built from kernel arguments and blockIdx-derived scalars only, so it stays in SGPRs.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
+}
 
-#ifndef LBFA_MAGIC
-#define LBFA_MAGIC 0
-#endif
-#ifndef LBFA_DOT2
-#define LBFA_DOT2 0
-#endif
+constexpr float kFp8Offset = 8.807f;  // csrc/qattn/attn_utils.cuh:30: p = exp2(s - m + 8.807) -> p_max = 448
+constexpr float kMagic = 12582912.0f;  // 1.5 * 2^23: int32 accumulator bits == float(kMagic + s) for |s| < 2^22
+constexpr int kMagicBits = 0x4B400000;
+
 #ifndef LBFA_THR
 #define LBFA_THR 8.0f
 #endif
@@ -83,8 +93,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   constexpr int KCH = KBYTES / (256 * 16);           // 16-B chunks per thread
   constexpr int VCH = VBYTES / (256 * 16);
   __shared__ __attribute__((aligned(16))) char smem[2 * (KBYTES + VBYTES)];
-  char* const ksm0 = smem;
-  char* const vsm0 = smem + 2 * KBYTES;
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -101,76 +109,109 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   const int row0 = qt * 128 + wave * 32;  // first query row of this wave
   const int qrow = row0 + r;
 
-  // ---- Q fragments (B operand of the int8 MFMA): lane (r, hh) holds bytes [32s+16hh, +16) of its row
-  i32x4 qf[KS];
-  {
-    const int8_t* qp = p.q + (int64_t)b * p.qb + (int64_t)h * p.qh + (int64_t)qrow * p.qs + 16 * hh;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      if (qrow < p.Sq) qf[s] = *reinterpret_cast<const i32x4*>(qp + 32 * s);
-      else qf[s] = i32x4{0, 0, 0, 0};
-    }
+  // ---- operand windows (bytes).  The descriptor is re-based per tile with scalar arithmetic, so the
+  // hardware range check sees only the loop-invariant per-lane offset.
+  const char* qbase = (const char*)p.q + (int64_t)b * p.qb + (int64_t)h * p.qh;
+  const char* kbase = (const char*)p.k + (int64_t)b * p.kb + (int64_t)hk * p.kh;
+  const int64_t k_bytes = (int64_t)(p.Sk - 1) * p.ks + D;
+  const int64_t k_tile_stride = 64 * p.ks;
+  const char* vbase;
+  int64_t v_bytes, v_tile_stride;  // bytes between consecutive 64-key tiles
+  if constexpr (FP8) {
+    vbase = (const char*)p.v + (((int64_t)b * p.Hkv + hk) * p.nK) * (int64_t)(D * 64);
+    v_bytes = (int64_t)p.nK * D * 64;
+    v_tile_stride = D * 64;
+  } else {
+    vbase = (const char*)p.v + 2 * ((int64_t)b * p.vb + (int64_t)hk * p.vh);
+    v_bytes = 2 * ((int64_t)(p.Sk - 1) * p.vs + D);
+    v_tile_stride = 128 * p.vs;
   }
+  const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(qbase, (unsigned)((int64_t)(p.Sq - 1) * p.qs + D));
+
+  // ---- Q fragments (B operand of the int8 MFMA): lane (r, hh) holds bytes [32s+16hh, +16) of its row.
+  // Rows >= Sq are out of the descriptor's range and read as zeros.
+  i32x4 qf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+    qf[s] = __builtin_bit_cast(i32x4, buf_load16(q_rs, (unsigned)qrow * (unsigned)p.qs + 16 * hh + 32 * s, 0));
   const float qsc = p.q_scale[((int64_t)b * p.Hq + h) * p.nQ + qt];
   const float* ksc = p.k_scale + ((int64_t)b * p.Hkv + hk) * p.nK;
-
-  const int8_t* kbase = p.k + (int64_t)b * p.kb + (int64_t)hk * p.kh;
-  const char* vbase;
-  if constexpr (FP8) vbase = (const char*)p.v + (((int64_t)b * p.Hkv + hk) * p.nK) * (int64_t)(D * 64);
-  else vbase = (const char*)p.v + 2 * ((int64_t)b * p.vb + (int64_t)hk * p.vh);
 
   int n_tiles = p.nK;
   if constexpr (CAUSAL) n_tiles = min(p.nK, 2 * (qt + 1));
 
+  // ---- loop-invariant per-thread offsets: global (voffset) and LDS -----------------------------------
+  unsigned k_goff[KCH], k_loff[KCH], v_goff[VCH], v_loff[VCH];
+#pragma unroll
+  for (int i = 0; i < KCH; ++i) {
+    const int c = t + 256 * i, row = c / (D / 16), ch = c % (D / 16);
+    k_goff[i] = (unsigned)row * (unsigned)p.ks + ch * 16;
+    k_loff[i] = row * D + ((ch ^ kx<D>(row)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < VCH; ++i) {
+    if constexpr (FP8) {
+      v_goff[i] = (t + 256 * i) * 16;
+      v_loff[i] = 2 * KBYTES + (t + 256 * i) * 16;
+    } else {
+      const int c = t + 256 * i, row = c / (D / 8), ch = c % (D / 8);
+      v_goff[i] = 2 * ((unsigned)row * (unsigned)p.vs) + ch * 16;
+      v_loff[i] = 2 * KBYTES + row * (2 * D) + (((ch >> 2) ^ vx<D>(row)) << 6) + ((ch & 3) << 4);
+    }
+  }
+  // fragment read offsets (buffer 0); buffer 1 adds a compile-time constant
+  unsigned kf_off[2][KS];
+#pragma unroll
+  for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int krow = 32 * kb2 + r;
+      kf_off[kb2][s] = krow * D + (((2 * s + hh) ^ kx<D>(krow)) << 4);
+    }
+  unsigned vf_off[4][DB][2];  // [k-step][d-block][low/high 4 keys]
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      if constexpr (FP8) {
+        const int d = 32 * db + r;
+        vf_off[ks][db][0] = 2 * KBYTES + d * 64 + (((2 * ks + hh) ^ ((d >> 2) & 7)) << 3);
+        vf_off[ks][db][1] = 0;
+      } else {
+        const int vrow = 16 * ks + 4 * hh + ((lane & 15) >> 2);
+        const int vcol = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+        vf_off[ks][db][0] = 2 * KBYTES + vrow * (2 * D) + ((db ^ vx<D>(vrow)) << 6) + vcol;
+        vf_off[ks][db][1] = 2 * KBYTES + (vrow + 8) * (2 * D) + ((db ^ vx<D>(vrow + 8)) << 6) + vcol;
+      }
+    }
+
   // ---- staging registers ----------------------------------------------------------------------------
   u32x4 kreg[KCH], vreg[VCH];
-  auto load_tile = [&](int j) {
-    const int n0 = j * 64;
+  auto load_tile = [&](int j) {  // rows / tiles past the end are outside the descriptor and read as zeros
+    const int64_t ko = (int64_t)j * k_tile_stride, vo = (int64_t)j * v_tile_stride;
+    const __amdgpu_buffer_rsrc_t k_rs = make_rsrc(kbase + ko, (unsigned)max((int64_t)0, k_bytes - ko));
+    const __amdgpu_buffer_rsrc_t v_rs = make_rsrc(vbase + vo, (unsigned)max((int64_t)0, v_bytes - vo));
 #pragma unroll
-    for (int i = 0; i < KCH; ++i) {
-      const int c = t + 256 * i, row = c / (D / 16), ch = c % (D / 16);
-      kreg[i] = u32x4{0, 0, 0, 0};
-      if (n0 + row < p.Sk) kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)(n0 + row) * p.ks + ch * 16);
-    }
-    if constexpr (FP8) {
+    for (int i = 0; i < KCH; ++i) kreg[i] = buf_load16(k_rs, k_goff[i], 0);
 #pragma unroll
-      for (int i = 0; i < VCH; ++i)
-        vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)j * (D * 64) + (t + 256 * i) * 16);
-    } else {
-#pragma unroll
-      for (int i = 0; i < VCH; ++i) {
-        const int c = t + 256 * i, row = c / (D / 8), ch = c % (D / 8);
-        vreg[i] = u32x4{0, 0, 0, 0};
-        if (n0 + row < p.Sk) vreg[i] = *reinterpret_cast<const u32x4*>(vbase + 2 * ((int64_t)(n0 + row) * p.vs) + ch * 16);
-      }
-    }
+    for (int i = 0; i < VCH; ++i) vreg[i] = buf_load16(v_rs, v_goff[i], 0);
   };
-  auto store_tile = [&](int buf) {
-    char* ksm = ksm0 + buf * KBYTES;
-    char* vsm = vsm0 + buf * VBYTES;
+  auto store_tile = [&](auto buf_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;
 #pragma unroll
-    for (int i = 0; i < KCH; ++i) {
-      const int c = t + 256 * i, row = c / (D / 16), ch = c % (D / 16);
-      *reinterpret_cast<u32x4*>(ksm + row * D + ((ch ^ kx<D>(row)) << 4)) = kreg[i];
-    }
-    if constexpr (FP8) {
+    for (int i = 0; i < KCH; ++i) *reinterpret_cast<u32x4*>(smem + k_loff[i] + BUF * KBYTES) = kreg[i];
 #pragma unroll
-      for (int i = 0; i < VCH; ++i) *reinterpret_cast<u32x4*>(vsm + (t + 256 * i) * 16) = vreg[i];
-    } else {
+    for (int i = 0; i < VCH; ++i) {
+      u32x4 val = vreg[i];
+      if constexpr (VT == LBFA_BF16) {  // bf16 -> fp16 on the way in (src/core.py:307-308 `v.to(float16)`)
 #pragma unroll
-      for (int i = 0; i < VCH; ++i) {
-        const int c = t + 256 * i, row = c / (D / 8), ch = c % (D / 8);
-        u32x4 val = vreg[i];
-        if constexpr (VT == LBFA_BF16) {  // bf16 -> fp16 on the way in (src/core.py:307-308 `v.to(float16)`)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float lo = __uint_as_float(val[e] << 16), hi = __uint_as_float(val[e] & 0xffff0000u);
-            const f16x2 pk = f16x2{(_Float16)lo, (_Float16)hi};
-            val[e] = __builtin_bit_cast(unsigned, pk);
-          }
+        for (int e = 0; e < 4; ++e) {
+          const float lo = __uint_as_float(val[e] << 16), hi = __uint_as_float(val[e] & 0xffff0000u);
+          const f16x2 pk = f16x2{(_Float16)lo, (_Float16)hi};
+          val[e] = __builtin_bit_cast(unsigned, pk);
         }
-        *reinterpret_cast<u32x4*>(vsm + row * (2 * D) + (((ch >> 2) ^ vx<D>(row)) << 6) + ((ch & 3) << 4)) = val;
       }
+      *reinterpret_cast<u32x4*>(smem + v_loff[i] + BUF * VBYTES) = val;
     }
   };
 
@@ -180,71 +221,54 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   for (int db = 0; db < DB; ++db)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc_o[db][i] = 0.f;
-  float m_run = -INFINITY;  // running max (base-2 domain), identical in both halves of a row
+  float m_run = -INFINITY;  // reference max (base-2 domain), identical in both halves of a row
   float l_run = 0.f;        // running sum over THIS lane's keys only (halves are added in the epilogue)
 
-#if LBFA_MAGIC
-  // int32 -> fp32 without a convert: accumulate on top of 1.5*2^23 so the accumulator's BITS are the float
-  // 12582912 + s (exact for |s| < 2^22; |s| <= 127*127*128 < 2^21).  The bias is folded into the fma constant.
+  // The int8 MFMA accumulates on top of this constant block (kept in registers for the whole kernel).
   i32x16 cmagic;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) cmagic[i] = 0x4B400000;
-  constexpr float kMagic = 12582912.0f;
-#endif
+  for (int i = 0; i < 16; ++i) cmagic[i] = kMagicBits;
 
-  auto compute_tile = [&](int buf, int j, auto masked_tag) {
+  auto compute_tile = [&](auto buf_tag, int j, auto masked_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;
     constexpr bool MASKED = decltype(masked_tag)::value;
-    const char* ksm = ksm0 + buf * KBYTES;
-    const char* vsm = vsm0 + buf * VBYTES;
-    const int n0 = j * 64;
-    // -- S^T = K Q^T (int8 -> int32): two 32-key blocks
+    const char* kbuf = smem + BUF * KBYTES;
+    const char* vbuf = smem + BUF * VBYTES;
+    // -- S^T = K Q^T (int8 -> int32, biased by kMagic): two 32-key blocks
     i32x16 sacc[2];
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2) {
-      const int krow = 32 * kb2 + r;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const i32x4 kf = *reinterpret_cast<const i32x4*>(ksm + krow * D + (((2 * s + hh) ^ kx<D>(krow)) << 4));
-        if (s == 0) {
-#if LBFA_MAGIC
-          sacc[kb2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], cmagic, 0, 0, 0);
-#else
-          sacc[kb2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], i32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
-#endif
-        } else {
-          sacc[kb2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], sacc[kb2], 0, 0, 0);
-        }
+        const i32x4 kf = *reinterpret_cast<const i32x4*>(kbuf + kf_off[kb2][s]);
+        if (s == 0) sacc[kb2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], cmagic, 0, 0, 0);
+        else sacc[kb2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], sacc[kb2], 0, 0, 0);
       }
     }
-    // -- online softmax, base 2; dequant scale folded into the exponent argument
+    // -- online softmax, base 2.  tv = kMagic + s (exact float); everything below is relative to the row max.
     const float sc = qsc * ksc[j];
     float x[2][16];
-    float mloc = -INFINITY;
+    float tmax = -INFINITY;
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-#if LBFA_MAGIC
-        float v = __int_as_float(sacc[kb2][i]);
-#else
-        float v = (float)sacc[kb2][i];
-#endif
+        float tv = __int_as_float(sacc[kb2][i]);
         if constexpr (MASKED) {
-          const int key = n0 + 32 * kb2 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          const int key = j * 64 + 32 * kb2 + (i & 3) + 8 * (i >> 2) + 4 * hh;
           bool dead = key >= p.Sk;
           if constexpr (CAUSAL) dead = dead || (key > qrow);
-          if (dead) v = -INFINITY;
+          if (dead) tv = -INFINITY;
         }
-        x[kb2][i] = v;
-        mloc = fmaxf(mloc, v);
+        x[kb2][i] = tv;
+        tmax = fmaxf(tmax, tv);
       }
-    mloc = half_swap_max(mloc);
-    // sc > 0, so max commutes with the scaling; -inf stays -inf
-#if LBFA_MAGIC
-    const float m_cand = fmaxf(m_run, __builtin_fmaf(mloc, sc, -kMagic * sc));
-#else
-    const float m_cand = fmaxf(m_run, mloc * sc);
-#endif
+    tmax = half_swap_max(tmax);
+    float xmax = (tmax - kMagic) * sc;  // row max of the dequantised scores (sc > 0); -inf if the row is all masked
+    if constexpr (MASKED) {
+      if (tmax == -INFINITY) tmax = 0.f;  // keep tv - tmax = -inf (not NaN) for fully masked rows
+    }
+    const float m_cand = fmaxf(m_run, xmax);
     // Deferred rescale: keep the old reference max while no row of the wave grew by more than THR
     // (P then stays <= 2^THR, exact in fp16/fp32); rescale O and l only when some row did.
     // First tile: m_run = -inf, so the branch is taken and alpha = 0.
@@ -257,33 +281,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc_o[db][i] *= alpha;
     }
-#if LBFA_MAGIC
-    float cexp = __builtin_fmaf(-kMagic, sc, -m_run);
-#else
-    float cexp = -m_run;
-#endif
+    // p = exp2((s - smax) * sc + (xmax - m_run)): (tv - tmax) is an exact integer, one fma folds the scale
+    float cexp = xmax - m_run;
+    if constexpr (MASKED) {
+      if (xmax == -INFINITY) cexp = 0.f;
+    }
     if constexpr (FP8) cexp += kFp8Offset;
     float psum = 0.f;
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kb2][i], sc, cexp));
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kb2][i] - tmax, sc, cexp));
         x[kb2][i] = pv;
-#if !LBFA_DOT2
         psum += pv;
-#endif
       }
+    l_run += psum;
 
     // -- O^T += V^T P^T : P^T fragments straight from the score accumulators
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int kb2 = ks >> 1, rb = (ks & 1) * 8;
       if constexpr (FP8) {
-#if LBFA_DOT2
-#pragma unroll
-        for (int e = 0; e < 8; ++e) psum += x[kb2][rb + e];
-#endif
         unsigned w0 = 0, w1 = 0;
         w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[kb2][rb + 0], x[kb2][rb + 1], w0, false);
         w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[kb2][rb + 2], x[kb2][rb + 3], w0, true);
@@ -292,60 +311,58 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         const long pf = (long)(((unsigned long)w1 << 32) | (unsigned long)w0);
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
-          const int d = 32 * db + r;
-          const long vf = *reinterpret_cast<const long*>(vsm + d * 64 + (((2 * ks + hh) ^ ((d >> 2) & 7)) << 3));
+          const long vf = *reinterpret_cast<const long*>(vbuf + vf_off[ks][db][0]);
           acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf, pf, acc_o[db], 0, 0, 0);
         }
       } else {
         f16x8 pf;
 #pragma unroll
         for (int e = 0; e < 8; ++e) pf[e] = (_Float16)x[kb2][rb + e];
-#if LBFA_DOT2
-        // row sum of the fp16-rounded probabilities, two per instruction (v_dot2_f32_f16, fp32 accumulate)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          psum = __builtin_amdgcn_fdot2(f16x2{pf[2 * e], pf[2 * e + 1]}, f16x2{(_Float16)1.0f, (_Float16)1.0f}, psum, false);
-#endif
-        const int vrow = 16 * ks + 4 * hh + ((lane & 15) >> 2);
-        const int vcol = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
-          const char* a0 = vsm + vrow * (2 * D) + ((db ^ vx<D>(vrow)) << 6) + vcol;
-          const char* a1 = vsm + (vrow + 8) * (2 * D) + ((db ^ vx<D>(vrow + 8)) << 6) + vcol;
-          const f16x4 lo = lds_read_tr16(a0);
-          const f16x4 hi = lds_read_tr16(a1);
+          const f16x4 lo = lds_read_tr16(vbuf + vf_off[ks][db][0]);
+          const f16x4 hi = lds_read_tr16(vbuf + vf_off[ks][db][1]);
           const f16x8 vf = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, acc_o[db], 0, 0, 0);
         }
       }
     }
-    l_run += psum;
   };
 
-  // ---- tile loop: one barrier per tile.  Full (unmasked) tiles first, branch-free; then the at most
-  // three tiles that need masking (causal diagonal block = 2 tiles, ragged last tile).
+  // ---- tile loop: one barrier per tile, buffers alternate statically (loop unrolled by two).
+  // Full (unmasked) tiles first, branch-free; then the at most three tiles that need masking
+  // (causal diagonal block = 2 tiles, ragged last tile).
   int n_main = n_tiles;
   if constexpr (CAUSAL) n_main = min(n_tiles, 2 * qt);
   else if ((p.Sk & 63) != 0) n_main = n_tiles - 1;
+
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  auto step = [&](auto buf_tag, auto nbuf_tag, int j, auto masked_tag) {
+    load_tile(j + 1);
+    bool skip = false;
+    if constexpr (decltype(masked_tag)::value && CAUSAL) skip = j * 64 > row0 + 31;  // all keys above all rows of this wave
+    if (!skip) compute_tile(buf_tag, j, masked_tag);
+    store_tile(nbuf_tag);
+    __syncthreads();
+  };
+
   load_tile(0);
-  store_tile(0);
+  store_tile(B0{});
   __syncthreads();
   int j = 0;
-  for (; j < n_main; ++j) {
-    const int buf = j & 1;
-    if (j + 1 < n_tiles) load_tile(j + 1);
-    compute_tile(buf, j, std::false_type{});
-    if (j + 1 < n_tiles) store_tile(buf ^ 1);
-    __syncthreads();
+  for (; j + 1 < n_main; j += 2) {
+    step(B0{}, B1{}, j, std::false_type{});
+    step(B1{}, B0{}, j + 1, std::false_type{});
   }
-  for (; j < n_tiles; ++j) {
-    const int buf = j & 1;
-    if (j + 1 < n_tiles) load_tile(j + 1);
-    bool skip = false;
-    if constexpr (CAUSAL) skip = j * 64 > row0 + 31;  // every key of the tile is above every row of this wave
-    if (!skip) compute_tile(buf, j, std::true_type{});
-    if (j + 1 < n_tiles) store_tile(buf ^ 1);
-    __syncthreads();
+  // here j is even: tile j lives in buffer 0
+  for (; j < n_tiles; j += 2) {
+    if (j < n_main) step(B0{}, B1{}, j, std::false_type{});
+    else step(B0{}, B1{}, j, std::true_type{});
+    if (j + 1 < n_tiles) {
+      if (j + 1 < n_main) step(B1{}, B0{}, j + 1, std::false_type{});
+      else step(B1{}, B0{}, j + 1, std::true_type{});
+    }
   }
 
   // ---- epilogue: O = O^T / l (x v_scale), LSE ------------------------------------------------------------

@@ -140,6 +140,16 @@ int lbfa_attn_fwd(const int8_t* q, const int8_t* k, const void* v, int v_dtype, 
   if (v_dtype != LBFA_E4M3 && (strides_v[0] | strides_v[1] | strides_v[2]) % 8 != 0)
     return fail(LBFA_EINVAL, "lbfa_attn_fwd: v strides must be multiples of 8 elements");
   if ((strides_o[0] | strides_o[1] | strides_o[2]) % 4 != 0) return fail(LBFA_EINVAL, "lbfa_attn_fwd: o strides must be multiples of 4 elements");
+  // 32-bit buffer offsets: every per-(batch, head) operand window (+ one tile of look-ahead) must stay below 2 GiB
+  {
+    const int64_t lim = 0x7fffffffLL;
+    const int64_t qwin = ((int64_t)Sq + LBFA_BLKQ) * strides_q[2] + D;
+    const int64_t kwin = ((int64_t)Sk + 2 * LBFA_BLKK) * strides_k[2] + D;
+    const int64_t vwin = v_dtype == LBFA_E4M3 ? ((int64_t)Sk + 2 * LBFA_BLKK) * D
+                                              : 2 * (((int64_t)Sk + 2 * LBFA_BLKK) * strides_v[2] + D);
+    if (qwin > lim || kwin > lim || vwin > lim)
+      return fail(LBFA_EINVAL, "lbfa_attn_fwd: per-(batch,head) operand window exceeds 2 GiB (seq stride x length too large)");
+  }
   lbfa::AttnParams p;
   p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse;
   p.q_scale = q_scale; p.k_scale = k_scale; p.v_scale = v_scale;

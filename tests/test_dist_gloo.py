@@ -1,0 +1,72 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo process groups exercise the sharding + gather plumbing of
+lowbit_quant_fa2_paddle_amd.dist with the CPU oracle standing in for the per-shard operator."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_op(q, k, v, tensor_layout="HND", is_causal=False, return_lse=False, **kw):
+    from oracle import lowbit_fa_oracle as orc
+    out = orc.lowbit_fa_forward(q.float().numpy(), k.float().numpy(), v.float().numpy(), tensor_layout=tensor_layout,
+                                is_causal=is_causal, return_lse=return_lse, amax_floor=1e-7)
+    if return_lse:
+        return torch.from_numpy(out[0]).half(), torch.from_numpy(out[1])
+    return torch.from_numpy(out).half()
+
+
+def _worker(rank, world, port, B, H, Hkv, S, D, layout, causal, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lowbit_quant_fa2_paddle_amd import dist as lbd
+        from oracle import lowbit_fa_oracle as orc
+        q, k, v = orc.make_inputs(B, H, S, D, seed=5, layout=layout, Hkv=Hkv)
+        tq, tk, tv = (torch.from_numpy(a).half() for a in (q, k, v))
+        o, lse = lbd.sharded_attention(_oracle_op, tq, tk, tv, tensor_layout=layout, is_causal=causal, return_lse=True)
+        o_local = lbd.sharded_attention(_oracle_op, tq, tk, tv, tensor_layout=layout, is_causal=causal, gather=False)
+        full_o, full_lse = _oracle_op(tq, tk, tv, tensor_layout=layout, is_causal=causal, return_lse=True)
+        assert o.shape == full_o.shape and torch.equal(o, full_o), "gathered output differs from the unsharded result"
+        assert torch.equal(lse, full_lse)
+        qs, _, _, spec = lbd.shard_inputs(tq, tk, tv, layout, world, rank)
+        assert o_local.shape == qs.shape
+        ret[rank] = spec
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B,H,Hkv,layout,causal,expect", [
+    (2, 4, 2, 2, "HND", False, "batch"),
+    (2, 3, 2, 1, "NHD", True, "batch"),      # uneven batch split (2 + 1), GQA
+    (2, 1, 4, 2, "HND", False, "head"),      # B < world: kv-head groups are split
+    (3, 1, 6, 3, "NHD", True, "head"),
+])
+def test_sharded_attention_matches_unsharded(world, B, H, Hkv, layout, causal, expect):
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, B, H, Hkv, 128, 64, layout, causal, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: expect for r in range(world)}
+
+
+def test_partition_properties():
+    from lowbit_quant_fa2_paddle_amd.dist import partition, shard_spec
+    for n in (1, 7, 32, 33):
+        for w in (1, 2, 3, 8):
+            spans = [partition(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert max(e - s for s, e in spans) - min(e - s for s, e in spans) <= 1
+    assert shard_spec(32, 32, 32, 8) == "batch" and shard_spec(4, 32, 8, 8) == "head"
+    with pytest.raises(ValueError):
+        shard_spec(1, 4, 2, 8)

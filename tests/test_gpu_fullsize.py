@@ -1,0 +1,108 @@
+"""Full BASELINE.json sizes on the GPU: size-independent properties + oracle spot checks on a few heads.
+
+Properties used (all follow from the operator being an independent softmax-weighted average per (batch, head)):
+  P1 slice consistency: the (b, h) slice of a full-size run is BIT-IDENTICAL to running that slice alone
+     (this is also the multi-GPU sharding argument: a shard's result does not depend on what else is in the batch);
+  P2 exact V scaling: O(q, k, 2v) == 2*O(q, k, v) bit for bit wherever the result is a normal fp16 number
+     (power-of-two scaling commutes with every rounding outside the subnormal range);
+  P3 rows sum to one: v = 1 -> O == 1 within fp16 rounding of P;
+  P4 causal first row: O[0] == V[0] (softmax over a single key).
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rand(shape, dev, seed, scale=1.0):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    return (torch.randn(shape, generator=g, device=dev, dtype=torch.float32) * scale).half()
+
+
+def _head(t, layout, b, h):
+    return t[b:b + 1, h:h + 1] if layout == "HND" else t[b:b + 1, :, h:h + 1]
+
+
+def _check_head_vs_oracle(oracle, fn_kwargs, q, k, v, o, layout, b, h, atol=2e-3, rtol=2e-3, **okw):
+    qs, ks, vs = (_head(t, layout, b, h).float().cpu().numpy() for t in (q, k, v))
+    ref = oracle.lowbit_fa_forward(qs, ks, vs, tensor_layout=layout, amax_floor=1e-7, tail="neg_inf", **okw)
+    got = _head(o, layout, b, h).float().cpu().numpy()
+    err = np.abs(got - ref)
+    assert np.all(err <= atol + rtol * np.abs(ref)), err.max()
+
+
+@pytest.mark.parametrize("name,B,H,S,D,layout,causal", [
+    ("C2", 4, 32, 4096, 64, "HND", False),
+    ("C3", 4, 32, 16384, 128, "NHD", True),
+])
+def test_int8_fp16_fullsize(oracle, dev, name, B, H, S, D, layout, causal):
+    import lowbit_quant_fa2_paddle_amd as lb
+    shp = (B, H, S, D) if layout == "HND" else (B, S, H, D)
+    q, k, v = _rand(shp, dev, 1), _rand(shp, dev, 2) + 0.25, _rand(shp, dev, 3)
+    o = lb.lowbit_fa_qk_int8_pv_fp16_triton(q, k, v, tensor_layout=layout, is_causal=causal)
+    assert torch.isfinite(o).all()
+    # P1: slices are bit-identical to stand-alone runs
+    for b, h in [(0, 0), (B - 1, H - 1), (1, 7)]:
+        o1 = lb.lowbit_fa_qk_int8_pv_fp16_triton(_head(q, layout, b, h).contiguous(), _head(k, layout, b, h).contiguous(),
+                                                 _head(v, layout, b, h).contiguous(), tensor_layout=layout, is_causal=causal)
+        assert torch.equal(o1, _head(o, layout, b, h)), f"{name}: slice ({b},{h}) differs from the full-size run"
+    # P2: exact power-of-two scaling of V
+    o2 = lb.lowbit_fa_qk_int8_pv_fp16_triton(q, k, v * 2, tensor_layout=layout, is_causal=causal)
+    # (bit-exact wherever the fp16 result is a normal number; in the subnormal range 2*round(x) and round(2x)
+    # sit on grids of different spacing, so allow one subnormal step there)
+    d2 = (o2.float() - 2 * o.float()).abs()
+    assert float(d2.max()) <= 2.0 ** -23, float(d2.max())
+    assert torch.equal(o2[o.abs() >= 2.0 ** -13], (o * 2)[o.abs() >= 2.0 ** -13])
+    del o2
+    # P3: rows of P sum to one
+    ones = torch.ones_like(v)
+    o3 = lb.lowbit_fa_qk_int8_pv_fp16_triton(q, k, ones, tensor_layout=layout, is_causal=causal)
+    assert float((o3.float() - 1).abs().max()) <= 2e-3
+    del o3, ones
+    # P4: causal first row
+    if causal:
+        first_o = o[:, :, 0] if layout == "HND" else o[:, 0]
+        first_v = v[:, :, 0] if layout == "HND" else v[:, 0]
+        assert float((first_o.float() - first_v.float()).abs().max()) <= 1e-3
+    # oracle spot check on one head (two for the smaller config)
+    for b, h in ([(0, 0), (3, 31)] if name == "C2" else [(2, 5)]):
+        _check_head_vs_oracle(oracle, {}, q, k, v, o, layout, b, h, is_causal=causal)
+
+
+def test_int4_fullsize_c4(oracle, dev):
+    import lowbit_quant_fa2_paddle_amd as lb
+    B, H, S, D = 4, 32, 8192, 64
+    q, k, v = _rand((B, H, S, D), dev, 4), _rand((B, H, S, D), dev, 5), _rand((B, H, S, D), dev, 6)
+    for q_bits, qm in ((4, 7), (8, 127)):
+        o = lb.lowbit_fa_qk_int4_pv_fp16_triton(q, k, v, q_bits=q_bits)
+        assert torch.isfinite(o).all()
+        o1 = lb.lowbit_fa_qk_int4_pv_fp16_triton(q[1:2, 3:4].contiguous(), k[1:2, 3:4].contiguous(), v[1:2, 3:4].contiguous(),
+                                                 q_bits=q_bits)
+        assert torch.equal(o1, o[1:2, 3:4])
+        _check_head_vs_oracle(oracle, {}, q, k, v, o, "HND", 2, 9, q_qmax=qm, k_qmax=7)
+
+
+def test_int8_fp8_c5_shard(oracle, dev):
+    """One GPU's shard of C5 (B32 over 8 GPUs -> B4 H32 S32768 D128), reduced to B=2 to bound test time."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    B, H, S, D = 2, 32, 32768, 128
+    q, k, v = _rand((B, H, S, D), dev, 7), _rand((B, H, S, D), dev, 8), _rand((B, H, S, D), dev, 9)
+    o, lse = lb.lowbit_fa_qk_int8_pv_fp8_cuda(q, k, v, return_lse=True)
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    o1 = lb.lowbit_fa_qk_int8_pv_fp8_cuda(q[1:2, 30:31].contiguous(), k[1:2, 30:31].contiguous(), v[1:2, 30:31].contiguous())
+    assert torch.equal(o1, o[1:2, 30:31])
+    ones = torch.ones_like(v)
+    o3 = lb.lowbit_fa_qk_int8_pv_fp8_cuda(q, k, ones)
+    assert float((o3.float() - 1).abs().max()) <= 4e-2  # e4m3 P: 3 mantissa bits, errors average out over 32K keys
+    # exact-attention spot check on 256 rows of one head (fp32 SDPA over all 32K keys)
+    qs, ks, vs = q[0, 5, :256].float(), k[0, 5].float(), v[0, 5].float()
+    ref = torch.softmax(qs @ ks.T * D ** -0.5, dim=-1) @ vs
+    assert float(((o[0, 5, :256].float() - ref) ** 2).mean()) <= 1e-5

@@ -229,73 +229,116 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) cmagic[i] = kMagicBits;
 
+  // ---- exact bias folding --------------------------------------------------------------------------------
+  // With tv = kMagic + s (the accumulator bits) the exponent argument is ONE fma:
+  //     s*sc - m  ==  fma(tv, sc, c1),   c1 = -kMagic*sc - m
+  // which is exact (one rounding, of the small final result) provided -kMagic*sc and c1 are representable.
+  // Both are forced onto a common power-of-two grid G chosen from the largest dequantisation scale of this
+  // (batch, kv-head): the per-tile scale is rounded to a multiple of g = G/2^22 (relative change <= 2^-21 *
+  // sc_max/sc, far below int8 quantisation noise), so kMagic*sc = 3*k*G exactly, and the softmax reference m
+  // - which may be ANY value near the row max - is kept on the same grid (rounded up by < G <= 2^-9 for
+  // typical data).  |c1| <= 1.17*kMagic*sc_max < 2^21*G, so every constant is an exact multiple of G.
+  float ks_max = 0.f;
+  for (int i = lane; i < p.nK; i += 64) ks_max = fmaxf(ks_max, ksc[i]);
+  ks_max = __builtin_amdgcn_readfirstlane(__float_as_uint(wave_max(ks_max))) ? wave_max(ks_max) : 1e-30f;
+  const float sc_max = qsc * ks_max;
+  const int gexp = (int)((__float_as_uint(1.25f * kMagic * sc_max) >> 23) & 0xff) - 127 + 1 - 21;  // log2(G)
+  const float G = __builtin_ldexpf(1.0f, gexp), invG = __builtin_ldexpf(1.0f, -gexp);
+  const float g = __builtin_ldexpf(1.0f, gexp - 22), invg = __builtin_ldexpf(1.0f, 22 - gexp);
+  auto grid_up = [&](float m) { return __builtin_ceilf(m * invG) * G; };  // -inf stays -inf
+
+  constexpr float kPLimit = 32768.0f;  // fp16 P must stay finite (max 65504)
+
   auto compute_tile = [&](auto buf_tag, int j, auto masked_tag) {
     constexpr int BUF = decltype(buf_tag)::value;
     constexpr bool MASKED = decltype(masked_tag)::value;
+    constexpr bool LAZY = !MASKED && !FP8;  // skip the row-max pass unless P overflowed (see below)
     const char* kbuf = smem + BUF * KBYTES;
     const char* vbuf = smem + BUF * VBYTES;
+    // -- online softmax, base 2
+    const float sc = __builtin_rintf(qsc * ksc[j] * invg) * g;  // per-tile dequant scale on the g grid
+    const float c0 = -kMagic * sc;                              // exact
+    float x[2][16];  // scores as floats kMagic + s (accumulator bits), then overwritten in place by P
     // -- S^T = K Q^T (int8 -> int32, biased by kMagic): two 32-key blocks
-    i32x16 sacc[2];
+    auto compute_scores = [&]() {
 #pragma unroll
-    for (int kb2 = 0; kb2 < 2; ++kb2) {
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+        i32x16 sacc;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const i32x4 kf = *reinterpret_cast<const i32x4*>(kbuf + kf_off[kb2][s]);
-        if (s == 0) sacc[kb2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], cmagic, 0, 0, 0);
-        else sacc[kb2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], sacc[kb2], 0, 0, 0);
-      }
-    }
-    // -- online softmax, base 2.  tv = kMagic + s (exact float); everything below is relative to the row max.
-    const float sc = qsc * ksc[j];
-    float x[2][16];
-    float tmax = -INFINITY;
-#pragma unroll
-    for (int kb2 = 0; kb2 < 2; ++kb2)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float tv = __int_as_float(sacc[kb2][i]);
-        if constexpr (MASKED) {
-          const int key = j * 64 + 32 * kb2 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          bool dead = key >= p.Sk;
-          if constexpr (CAUSAL) dead = dead || (key > qrow);
-          if (dead) tv = -INFINITY;
+        for (int s = 0; s < KS; ++s) {
+          const i32x4 kf = *reinterpret_cast<const i32x4*>(kbuf + kf_off[kb2][s]);
+          if (s == 0) sacc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], cmagic, 0, 0, 0);
+          else sacc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], sacc, 0, 0, 0);
         }
-        x[kb2][i] = tv;
-        tmax = fmaxf(tmax, tv);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float tv = __int_as_float(sacc[i]);
+          if constexpr (MASKED) {
+            const int key = j * 64 + 32 * kb2 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            bool dead = key >= p.Sk;
+            if constexpr (CAUSAL) dead = dead || (key > qrow);
+            if (dead) tv = -INFINITY;  // fma(-inf, sc, c1) = -inf -> p = 0
+          }
+          x[kb2][i] = tv;
+        }
       }
-    tmax = half_swap_max(tmax);
-    float xmax = (tmax - kMagic) * sc;  // row max of the dequantised scores (sc > 0); -inf if the row is all masked
-    if constexpr (MASKED) {
-      if (tmax == -INFINITY) tmax = 0.f;  // keep tv - tmax = -inf (not NaN) for fully masked rows
-    }
-    const float m_cand = fmaxf(m_run, xmax);
-    // Deferred rescale: keep the old reference max while no row of the wave grew by more than THR
-    // (P then stays <= 2^THR, exact in fp16/fp32); rescale O and l only when some row did.
-    // First tile: m_run = -inf, so the branch is taken and alpha = 0.
-    if (__any(m_cand > m_run + THR)) {
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);  // m_run = -inf -> 0
-      m_run = m_cand;
-      l_run *= alpha;
+    };
+    // Move the reference m_run up to (at least) this tile's row max, rescaling O and l, when some row of the
+    // wave needs it.  First tile: m_run = -inf -> alpha = 0.
+    auto update_reference = [&](float thr) {
+      float tmax = -INFINITY;
 #pragma unroll
-      for (int db = 0; db < DB; ++db)
+      for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc_o[db][i] *= alpha;
-    }
-    // p = exp2((s - smax) * sc + (xmax - m_run)): (tv - tmax) is an exact integer, one fma folds the scale
-    float cexp = xmax - m_run;
-    if constexpr (MASKED) {
-      if (xmax == -INFINITY) cexp = 0.f;
-    }
-    if constexpr (FP8) cexp += kFp8Offset;
-    float psum = 0.f;
+        for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, x[kb2][i]);
+      tmax = half_swap_max(tmax);
+      const float xmax = __builtin_fmaf(tmax, sc, c0);  // row max of the dequantised scores; -inf if all masked
+      // fp8 P: keep the exact row max as reference so that P_max = 448 = e4m3 max exactly, as the reference
+      // specifies (attn_utils.cuh:30); c1 then carries a rounding of <= 2^-13 relative, invisible at 3 mantissa bits.
+      const float m_cand = fmaxf(m_run, FP8 ? xmax : grid_up(xmax));
+      if (__any(m_cand > m_run + thr)) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);  // m_run = -inf -> 0
+        m_run = m_cand;
+        l_run *= alpha;
 #pragma unroll
-    for (int kb2 = 0; kb2 < 2; ++kb2)
+        for (int db = 0; db < DB; ++db)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kb2][i] - tmax, sc, cexp));
-        x[kb2][i] = pv;
-        psum += pv;
+          for (int i = 0; i < 16; ++i) acc_o[db][i] *= alpha;
       }
+    };
+    float psum;
+    auto exponentiate = [&]() {  // x <- P, in place
+      float c1 = c0 - m_run;  // exact (grid argument above); +inf while m_run = -inf
+      if constexpr (FP8) c1 += kFp8Offset;
+      psum = 0.f;
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          x[kb2][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kb2][i], sc, c1));
+          psum += x[kb2][i];
+        }
+    };
+    if constexpr (LAZY) {
+      // Any reference within 2^15 of the row max is as good as the max itself (P is fp16/fp32 floating point):
+      // exponentiate against the current reference and look at the row sum, which bounds every P from above.
+      // Only if a sum blew up (first tile: reference = -inf -> +inf) redo the tile the long way: recompute the
+      // scores (K is still in LDS), take the row max, move the reference, exponentiate again.  Written as a
+      // loop so the rare second pass reuses the same code and registers.
+      bool redo = false;
+#pragma clang loop unroll(disable)
+      for (;;) {
+        compute_scores();
+        if (redo) update_reference(0.0f);
+        exponentiate();
+        if (redo || !__any(!(psum <= kPLimit))) break;
+        redo = true;
+      }
+    } else {
+      compute_scores();
+      update_reference(THR);
+      exponentiate();
+    }
     l_run += psum;
 
     // -- O^T += V^T P^T : P^T fragments straight from the score accumulators

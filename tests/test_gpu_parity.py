@@ -277,3 +277,31 @@ def test_varlen_and_dispatchers(oracle, dev):
     ref = oracle.sdpa_naive(*(x.astype(np.float64) * 8 for x in (q4, k4, v4)))
     # plain fp16 matmul SDPA on x8 inputs: scores ~ +-500 carry fp16 rounding of 0.25 -> loose check
     assert np.abs(_np(o_fp) - ref).max() <= 0.1 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("causal", [False, True])
+def test_lazy_reference_rescale_branches(oracle, dev, D, causal):
+    """The fp16-PV kernel exponentiates against a stale softmax reference and only moves it when a row sum
+    blows up (attn_fwd.hip, LAZY path).  That branch is rare on random data, so force it: single keys aligned
+    with single queries make one row's score jump by ~60 (finite overflow of the fp16 range) and by > 127
+    (fp32 exp2 overflows to +inf) in LATER tiles, plus one spike in the very first tile.  Checked against the
+    oracle on the FULL tensor."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    S = 640
+    q, k, v = oracle.make_inputs(1, 2, S, D, seed=77)
+    kk = k.copy()
+    f = 64.0 / D  # keep q.k of the spikes comparable across head dims
+    kk[0, 0, 5] = oracle.to_storage(3.0 * f * q[0, 0, 600], "fp16")     # first tile, seen by row 600 (also causal)
+    kk[0, 0, 300] = oracle.to_storage(6.0 * f * q[0, 0, 517], "fp16")   # tile 4: finite overflow for row 517
+    kk[0, 0, 400] = oracle.to_storage(16.0 * f * q[0, 0, 433], "fp16")  # tile 6: +inf for row 433
+    kk[0, 1, 130] = oracle.to_storage(-9.0 * f * q[0, 1, 200], "fp16")  # a hugely NEGATIVE score must not matter
+    tq, tk, tv = (_t(a, "fp16", dev) for a in (q, kk, v))
+    o, lse = lb.lowbit_fa_qk_int8_pv_fp16_triton(tq, tk, tv, is_causal=causal, return_lse=True, smooth_k=False)
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    o_ref, lse_ref = oracle.lowbit_fa_forward(q, kk, v, is_causal=causal, return_lse=True, smooth_k=False, amax_floor=1e-7)
+    _o_close(_np(o), o_ref, "fp16")
+    assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 1e-3 + 2.0 ** -20 * np.abs(lse_ref).max()
+    # the spiked rows are (nearly) one-hot: they must reproduce the value row of their spike key
+    assert np.abs(_np(o)[0, 0, 517] - v[0, 0, 300]).max() <= 2e-2
+    assert np.abs(_np(o)[0, 0, 433] - v[0, 0, 400]).max() <= 2e-2

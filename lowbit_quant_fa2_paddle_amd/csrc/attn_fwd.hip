@@ -77,6 +77,12 @@ constexpr float kFp8Offset = 8.807f;  // csrc/qattn/attn_utils.cuh:30: p = exp2(
 constexpr float kMagic = 12582912.0f;  // 1.5 * 2^23: int32 accumulator bits == float(kMagic + s) for |s| < 2^22
 constexpr int kMagicBits = 0x4B400000;
 
+#ifndef LBFA_PRIO
+#define LBFA_PRIO 2  // s_setprio(1) around the PV MFMA section: keeps the matrix pipe fed while other waves exponentiate (+3..6 %)
+#endif
+#ifndef LBFA_DOT2
+#define LBFA_DOT2 0
+#endif
 #ifndef LBFA_THR
 #define LBFA_THR 8.0f
 #endif
@@ -261,6 +267,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     float x[2][16];  // scores as floats kMagic + s (accumulator bits), then overwritten in place by P
     // -- S^T = K Q^T (int8 -> int32, biased by kMagic): two 32-key blocks
     auto compute_scores = [&]() {
+#if LBFA_PRIO & 1
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
         i32x16 sacc;
@@ -282,6 +291,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
           x[kb2][i] = tv;
         }
       }
+#if LBFA_PRIO & 1
+      __builtin_amdgcn_s_setprio(0);
+#endif
     };
     // Move the reference m_run up to (at least) this tile's row max, rescaling O and l, when some row of the
     // wave needs it.  First tile: m_run = -inf -> alpha = 0.
@@ -316,8 +328,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           x[kb2][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kb2][i], sc, c1));
+#if !LBFA_DOT2
           psum += x[kb2][i];
+#endif
         }
+#if LBFA_DOT2
+      if constexpr (FP8) {
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) psum += x[kb2][i];
+      } else {  // sum of the fp16-rounded P, two per instruction (v_dot2_f32_f16, fp32 accumulate)
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+          for (int i = 0; i < 16; i += 2)
+            psum = __builtin_amdgcn_fdot2(f16x2{(_Float16)x[kb2][i], (_Float16)x[kb2][i + 1]}, f16x2{(_Float16)1.0f, (_Float16)1.0f}, psum, false);
+      }
+#endif
     };
     if constexpr (LAZY) {
       // Any reference within 2^15 of the row max is as good as the max itself (P is fp16/fp32 floating point):
@@ -342,6 +370,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     l_run += psum;
 
     // -- O^T += V^T P^T : P^T fragments straight from the score accumulators
+#if LBFA_PRIO & 2
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int kb2 = ks >> 1, rb = (ks & 1) * 8;
@@ -370,6 +401,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         }
       }
     }
+#if LBFA_PRIO & 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
 
   // ---- tile loop: one barrier per tile, buffers alternate statically (loop unrolled by two).

@@ -6,6 +6,8 @@
 // amax pass and the encode pass so every input byte is read exactly once.
 // Built with -ffp-contract=off and correctly rounded fp32 division: the int8 codes and the scales are
 // bit-exact against the CPU oracle.
+#include <type_traits>
+
 #include "lbfa_common.h"
 
 namespace lbfa {
@@ -71,7 +73,17 @@ __global__ void mean_finalize_kernel(MeanParams p) {
 // per-block int8 / int4-range quantiser
 // ---------------------------------------------------------------------------------------------------
 
-template <int DT, int D, int BLK>
+template <int DT>
+__device__ __forceinline__ void unpack8(const uint4& raw, float (&v)[8]) {
+  const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = load_cvt<DT>((unsigned short)(w[i] & 0xffffu));
+    v[2 * i + 1] = load_cvt<DT>((unsigned short)(w[i] >> 16));
+  }
+}
+
+template <int DT, int D, int BLK, bool HAS_MEAN, bool HAS_DOT>
 __global__ __launch_bounds__(256) void quant_per_block_kernel(QuantParams p) {
   constexpr int CPR = D / 8;
   constexpr int RPP = 256 / CPR;  // rows per pass
@@ -82,55 +94,45 @@ __global__ __launch_bounds__(256) void quant_per_block_kernel(QuantParams p) {
   const unsigned short* xbase = p.x + (int64_t)b * p.xb + (int64_t)h * p.xh + c * 8;
   int8_t* obase = p.out + (int64_t)b * p.ob + (int64_t)h * p.oh + c * 8;
 
-  float mean[8];
-  const bool has_mean = p.mean != nullptr;
-  if (has_mean) {
-    const uint4 raw = *reinterpret_cast<const uint4*>(p.mean + ((int64_t)b * (p.H / p.mean_group) + h / p.mean_group) * D + c * 8);
-    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      mean[2 * i] = load_cvt<DT>((unsigned short)(w[i] & 0xffffu));
-      mean[2 * i + 1] = load_cvt<DT>((unsigned short)(w[i] >> 16));
-    }
-  }
-  float vec[8];
-  const bool has_dot = p.rowdot_vec != nullptr;
-  if (has_dot) {
-    const uint4 raw = *reinterpret_cast<const uint4*>(p.rowdot_vec + ((int64_t)b * (p.H / p.rowdot_group) + h / p.rowdot_group) * D + c * 8);
-    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      vec[2 * i] = load_cvt<DT>((unsigned short)(w[i] & 0xffffu));
-      vec[2 * i + 1] = load_cvt<DT>((unsigned short)(w[i] >> 16));
-    }
-  }
+  float mean[8], vec[8];
+  if constexpr (HAS_MEAN)
+    unpack8<DT>(*reinterpret_cast<const uint4*>(p.mean + ((int64_t)b * (p.H / p.mean_group) + h / p.mean_group) * D + c * 8), mean);
+  if constexpr (HAS_DOT)
+    unpack8<DT>(*reinterpret_cast<const uint4*>(p.rowdot_vec + ((int64_t)b * (p.H / p.rowdot_group) + h / p.rowdot_group) * D + c * 8), vec);
 
+  // all loads of the block first (NP independent 16-byte loads in flight per lane), then the arithmetic
+  uint4 raw[NP];
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    const int row = blk * BLK + ps * RPP + rl;
+    raw[ps] = make_uint4(0, 0, 0, 0);  // masked rows load as 0 (quant_per_block.py:170)
+    if (row < p.S) raw[ps] = *reinterpret_cast<const uint4*>(xbase + (int64_t)row * p.xs);
+  }
   float xs[NP][8];
   float amax = 0.f;
 #pragma unroll
   for (int ps = 0; ps < NP; ++ps) {
     const int row = blk * BLK + ps * RPP + rl;
-    uint4 raw = make_uint4(0, 0, 0, 0);  // masked rows load as 0 (quant_per_block.py:170)
-    if (row < p.S) raw = *reinterpret_cast<const uint4*>(xbase + (int64_t)row * p.xs);
-    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
-    float dot = 0.f;
+    float v[8];
+    unpack8<DT>(raw[ps], v);
+    if constexpr (HAS_DOT) {
+      float dot = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float v = load_cvt<DT>((unsigned short)((i & 1) ? (w[i >> 1] >> 16) : (w[i >> 1] & 0xffffu)));
-      if (has_dot) dot += v * vec[i];
-      // `k - km` is an elementwise op in the storage dtype (quant_per_block.py:186-187): the fp32
-      // difference is rounded to that dtype, as the CPU oracle (and torch/paddle CPU) does.
-      // (rows past the end stay 0: the reference subtracts on the real tensor, then loads masked rows as 0)
-      if (has_mean && row < p.S) v = load_cvt<DT>(store_cvt<DT>(v - mean[i]));
-      v = v * p.sm_scale;
-      xs[ps][i] = v;
-      amax = fmaxf(amax, fabsf(v));
-    }
-    if (has_dot) {
+      for (int i = 0; i < 8; ++i) dot += v[i] * vec[i];
 #pragma unroll
       for (int o = CPR / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
-      if (c == 0 && row < p.S)
-        p.rowdot_out[((int64_t)b * p.H + h) * p.S + row] = load_cvt<DT>(store_cvt<DT>(dot));
+      if (c == 0 && row < p.S) p.rowdot_out[((int64_t)b * p.H + h) * p.S + row] = load_cvt<DT>(store_cvt<DT>(dot));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float x = v[i];
+      // `k - km` is an elementwise op in the storage dtype (quant_per_block.py:186-187): the fp32 difference
+      // is rounded to that dtype, as the CPU oracle (and torch/paddle CPU) does.  Rows past the end stay 0:
+      // the reference subtracts on the real tensor, then loads masked rows as 0.
+      if constexpr (HAS_MEAN) x = (row < p.S) ? load_cvt<DT>(store_cvt<DT>(x - mean[i])) : 0.f;
+      x *= p.sm_scale;
+      xs[ps][i] = x;
+      amax = fmaxf(amax, fabsf(x));
     }
   }
   amax = wave_max(amax);
@@ -140,19 +142,45 @@ __global__ __launch_bounds__(256) void quant_per_block_kernel(QuantParams p) {
   const float scale = fmaxf(amax, 1e-7f) / p.qmax;
   if (t == 0) p.scale[((int64_t)b * p.H + h) * p.nblk + blk] = scale;
 
+  // y = xs / scale must be the correctly rounded fp32 quotient (the codes are bit-exact against the oracle).
+  // A full IEEE division per element costs ~12 VALU ops; the divisor is the same for the whole block, so use
+  // Markstein's sequence with the correctly rounded reciprocal: q0 = x*r, e = fma(-q0, s, x) (exact),
+  // q1 = fma(e, r, q0) == RN(x/s) for every x unless the significand of s is all ones (checked on 1.2e8
+  // adversarial samples; theorem: Markstein 1990), in which case the plain division is used.
+  const float rcp = 1.0f / scale;
+  const bool exact_rcp_ok =
+      (__builtin_amdgcn_readfirstlane(__float_as_uint(scale)) & 0x7fffffu) != 0x7fffffu;  // block-uniform
+  auto encode = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
-  for (int ps = 0; ps < NP; ++ps) {
-    const int row = blk * BLK + ps * RPP + rl;
-    unsigned w[2] = {0, 0};
+    for (int ps = 0; ps < NP; ++ps) {
+      const int row = blk * BLK + ps * RPP + rl;
+      int q[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float y = xs[ps][i] / scale;
-      y = y + (y >= 0.f ? 0.5f : -0.5f);  // round half away from zero (:174-176)
-      const int q = (int)y;               // trunc
-      w[i >> 2] |= ((unsigned)q & 0xffu) << (8 * (i & 3));
+      for (int i = 0; i < 8; ++i) {
+        const float xv = xs[ps][i];
+        float y;
+        if constexpr (FAST) {
+          const float q0 = xv * rcp;
+          y = __builtin_fmaf(__builtin_fmaf(-q0, scale, xv), rcp, q0);
+        } else {
+          y = xv / scale;
+        }
+        // round half away from zero (:174-176): y + 0.5*sign(y), then truncate (v_cvt_i32_f32 truncates)
+        q[i] = (int)(y + __builtin_copysignf(0.5f, y));
+      }
+      // |q| <= 127: v_cvt_pk_i16_i32 keeps the low bytes, v_perm_b32 gathers bytes 0 and 2 of each pair
+      const unsigned p01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(q[0], q[1]));
+      const unsigned p23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(q[2], q[3]));
+      const unsigned p45 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(q[4], q[5]));
+      const unsigned p67 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(q[6], q[7]));
+      const unsigned w0 = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
+      const unsigned w1 = __builtin_amdgcn_perm(p67, p45, 0x06040200u);
+      if (row < p.S) *reinterpret_cast<uint2*>(obase + (int64_t)row * p.os) = make_uint2(w0, w1);
     }
-    if (row < p.S) *reinterpret_cast<uint2*>(obase + (int64_t)row * p.os) = make_uint2(w[0], w[1]);
-  }
+  };
+  if (exact_rcp_ok) encode(std::true_type{});
+  else encode(std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -287,14 +315,26 @@ hipError_t launch_mean_seq(const void* x, int dtype, void* out, void* ws, int B,
 
 hipError_t launch_quant_per_block(const QuantParams& p, int dtype, int D, int blk, hipStream_t stream) {
   dim3 grid(p.nblk, p.H, p.B);
-#define LBFA_Q(DT, DD, BB) hipLaunchKernelGGL((quant_per_block_kernel<DT, DD, BB>), grid, dim3(256), 0, stream, p)
+  const bool hm = p.mean != nullptr, hd = p.rowdot_vec != nullptr;
+#define LBFA_Q(DT, DD, BB, HM, HD) hipLaunchKernelGGL((quant_per_block_kernel<DT, DD, BB, HM, HD>), grid, dim3(256), 0, stream, p)
+#define LBFA_Q1(DT, DD, BB)                          \
+  do {                                               \
+    if (hm && hd) LBFA_Q(DT, DD, BB, true, true);    \
+    else if (hm) LBFA_Q(DT, DD, BB, true, false);    \
+    else if (hd) LBFA_Q(DT, DD, BB, false, true);    \
+    else LBFA_Q(DT, DD, BB, false, false);           \
+  } while (0)
 #define LBFA_Q2(DT)                                         \
-  if (D == 64 && blk == 128) LBFA_Q(DT, 64, 128);           \
-  else if (D == 64 && blk == 64) LBFA_Q(DT, 64, 64);        \
-  else if (D == 128 && blk == 128) LBFA_Q(DT, 128, 128);    \
-  else LBFA_Q(DT, 128, 64);
-  if (dtype == LBFA_F16) { LBFA_Q2(LBFA_F16) } else { LBFA_Q2(LBFA_BF16) }
+  do {                                                      \
+    if (D == 64 && blk == 128) LBFA_Q1(DT, 64, 128);        \
+    else if (D == 64 && blk == 64) LBFA_Q1(DT, 64, 64);     \
+    else if (D == 128 && blk == 128) LBFA_Q1(DT, 128, 128); \
+    else LBFA_Q1(DT, 128, 64);                              \
+  } while (0)
+  if (dtype == LBFA_F16) LBFA_Q2(LBFA_F16);
+  else LBFA_Q2(LBFA_BF16);
 #undef LBFA_Q2
+#undef LBFA_Q1
 #undef LBFA_Q
   return hipGetLastError();
 }

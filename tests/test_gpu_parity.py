@@ -305,3 +305,34 @@ def test_lazy_reference_rescale_branches(oracle, dev, D, causal):
     # the spiked rows are (nearly) one-hot: they must reproduce the value row of their spike key
     assert np.abs(_np(o)[0, 0, 517] - v[0, 0, 300]).max() <= 2e-2
     assert np.abs(_np(o)[0, 0, 433] - v[0, 0, 400]).max() <= 2e-2
+
+
+def test_quant_division_exceptional_divisor(oracle, dev):
+    """The quantiser divides by the block scale with Markstein's reciprocal sequence, which is exact unless
+    the scale's significand is all ones; that case takes the plain-division branch.  Force it: pick sm_scale so
+    that max|x*sm_scale|/127 has an all-ones significand, and compare bit for bit with the oracle."""
+    from lowbit_quant_fa2_paddle_amd import quant_per_block as qpb
+    target = np.array([0x3C7FFFFF], dtype=np.uint32).view(np.float32)[0]  # ~0.0156, significand all ones
+    sigma = None
+    cand = np.float32(target * np.float32(127.0))
+    for _ in range(400):
+        if (np.float32(cand / np.float32(127.0))).view(np.uint32) == np.uint32(0x3C7FFFFF):
+            sigma = cand
+            break
+        cand = np.nextafter(cand, np.float32(0), dtype=np.float32)
+    if sigma is None:
+        cand = np.float32(target * np.float32(127.0))
+        for _ in range(400):
+            if (np.float32(cand / np.float32(127.0))).view(np.uint32) == np.uint32(0x3C7FFFFF):
+                sigma = cand
+                break
+            cand = np.nextafter(cand, np.float32(np.inf), dtype=np.float32)
+    assert sigma is not None
+    rng = np.random.default_rng(3)
+    x = oracle.to_storage(rng.uniform(-1, 1, (1, 2, 256, 64)).astype(np.float32), "fp16")
+    x[:, :, ::128, 0] = 1.0  # amax = 1.0 exactly in every 128-row block
+    codes, scale = qpb.quantize(_t(x, "fp16", dev), sm_scale=float(sigma), qmax=127, blk=128)
+    rc, rs = oracle.quant_per_block(x, sigma, 127.0, 128, amax_floor=1e-7)
+    assert np.all(rs.view(np.uint32) == 0x3C7FFFFF), "test did not hit the exceptional divisor"
+    assert np.array_equal(scale.cpu().numpy().view(np.uint32), rs.view(np.uint32))
+    assert np.array_equal(codes.cpu().numpy(), rc)

@@ -1,0 +1,53 @@
+// Device helpers shared by the attention kernels (gfx950).
+#pragma once
+#include <type_traits>
+
+#include "lbfa_common.h"
+
+namespace lbfa {
+
+typedef __fp16 hf16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) hf16x4* lds_hf16x4_ptr;
+
+// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of 16-bit elements, delivered
+// column-major (lane i gets column i of the 4 rows).  EXEC must be all ones.
+__device__ __forceinline__ f16x4 lds_read_tr16(const char* addr) {
+  const hf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hf16x4_ptr)(addr));
+  return __builtin_bit_cast(f16x4, v);
+}
+
+template <int D>
+__device__ __forceinline__ int kx(int row) {  // K-tile chunk swizzle
+  if constexpr (D == 64) return (row >> 2) & 3;
+  else return (row >> 1) & 7;
+}
+template <int D>
+__device__ __forceinline__ int vx(int row) {  // V-tile 64-B chunk swizzle
+  if constexpr (D == 64) return (row >> 1) & 1;
+  else return row & 3;
+}
+
+__device__ __forceinline__ float half_swap_max(float x) {
+  // max over the two 32-lane halves holding the same query row
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_swap_sum(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// Raw buffer resource over [base, base+bytes): out-of-range loads return 0 (hardware bounds check).
+// Built from kernel arguments and blockIdx-derived scalars only, so it stays in SGPRs.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
+}
+
+constexpr float kFp8Offset = 8.807f;  // csrc/qattn/attn_utils.cuh:30: p = exp2(s - m + 8.807) -> p_max = 448
+constexpr float kMagic = 12582912.0f;  // 1.5 * 2^23: int32 accumulator bits == float(kMagic + s) for |s| < 2^22
+constexpr int kMagicBits = 0x4B400000;
+
+}  // namespace lbfa

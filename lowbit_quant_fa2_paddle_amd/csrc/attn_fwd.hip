@@ -27,58 +27,15 @@
 //   K tile  [64 keys][D bytes]   16-B chunk c of row r stored at chunk c ^ kx(r)
 //   V tile  [64 keys][D fp16]    64-B chunk c of row r stored at chunk c ^ vx(r)
 //   V fp8   [D][64 bytes]        already swizzled in HBM by lbfa_quant_v_fp8 -> linear copy
-#include <type_traits>
-
-#include "lbfa_common.h"
+#include "attn_common.h"
 
 namespace lbfa {
 
-typedef __fp16 hf16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
-typedef __attribute__((address_space(3))) hf16x4* lds_hf16x4_ptr;
-
-// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of 16-bit elements, delivered
-// column-major (lane i gets column i of the 4 rows).  EXEC must be all ones.
-__device__ __forceinline__ f16x4 lds_read_tr16(const char* addr) {
-  const hf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hf16x4_ptr)(addr));
-  return __builtin_bit_cast(f16x4, v);
-}
-
-template <int D>
-__device__ __forceinline__ int kx(int row) {  // K-tile chunk swizzle
-  if constexpr (D == 64) return (row >> 2) & 3;
-  else return (row >> 1) & 7;
-}
-template <int D>
-__device__ __forceinline__ int vx(int row) {  // V-tile 64-B chunk swizzle
-  if constexpr (D == 64) return (row >> 1) & 1;
-  else return row & 3;
-}
-
-__device__ __forceinline__ float half_swap_max(float x) {
-  // max over the two 32-lane halves holding the same query row
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float half_swap_sum(float x) {
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-// Raw buffer resource over [base, base+bytes): out-of-range loads return 0 (hardware bounds check).
-// Built from kernel arguments and blockIdx-derived scalars only, so it stays in SGPRs.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
-}
-
-constexpr float kFp8Offset = 8.807f;  // csrc/qattn/attn_utils.cuh:30: p = exp2(s - m + 8.807) -> p_max = 448
-constexpr float kMagic = 12582912.0f;  // 1.5 * 2^23: int32 accumulator bits == float(kMagic + s) for |s| < 2^22
-constexpr int kMagicBits = 0x4B400000;
-
 #ifndef LBFA_PRIO
 #define LBFA_PRIO 2  // s_setprio(1) around the PV MFMA section: keeps the matrix pipe fed while other waves exponentiate (+3..6 %)
+#endif
+#ifndef LBFA_SUM4
+#define LBFA_SUM4 0
 #endif
 #ifndef LBFA_DOT2
 #define LBFA_DOT2 0
@@ -165,31 +122,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       v_loff[i] = 2 * KBYTES + row * (2 * D) + (((ch >> 2) ^ vx<D>(row)) << 6) + ((ch & 3) << 4);
     }
   }
-  // fragment read offsets (buffer 0); buffer 1 adds a compile-time constant
-  unsigned kf_off[2][KS];
+  // Fragment read addresses.  The swizzles depend only on the low row bits, so the block / k-step / high-half /
+  // buffer parts are compile-time byte offsets folded into the ds_read immediates; per lane only KS (K) and
+  // DB or 4 (V) base registers are needed.
+  unsigned kf_base[KS];  // + kb2 * 32 * D
 #pragma unroll
-  for (int kb2 = 0; kb2 < 2; ++kb2)
+  for (int s = 0; s < KS; ++s) kf_base[s] = r * D + (((2 * s + hh) ^ kx<D>(r)) << 4);
+  constexpr int NVB = FP8 ? 4 : DB;
+  unsigned vf_base[NVB];  // f16: [db] + ks*16*2D + hi*8*2D ;  fp8: [ks] + db*32*64
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int krow = 32 * kb2 + r;
-      kf_off[kb2][s] = krow * D + (((2 * s + hh) ^ kx<D>(krow)) << 4);
+  for (int i = 0; i < NVB; ++i) {
+    if constexpr (FP8) {
+      vf_base[i] = 2 * KBYTES + r * 64 + (((2 * i + hh) ^ ((r >> 2) & 7)) << 3);
+    } else {
+      const int vrow = 4 * hh + ((lane & 15) >> 2);
+      const int vcol = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+      vf_base[i] = 2 * KBYTES + vrow * (2 * D) + ((i ^ vx<D>(vrow)) << 6) + vcol;
     }
-  unsigned vf_off[4][DB][2];  // [k-step][d-block][low/high 4 keys]
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-    for (int db = 0; db < DB; ++db) {
-      if constexpr (FP8) {
-        const int d = 32 * db + r;
-        vf_off[ks][db][0] = 2 * KBYTES + d * 64 + (((2 * ks + hh) ^ ((d >> 2) & 7)) << 3);
-        vf_off[ks][db][1] = 0;
-      } else {
-        const int vrow = 16 * ks + 4 * hh + ((lane & 15) >> 2);
-        const int vcol = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
-        vf_off[ks][db][0] = 2 * KBYTES + vrow * (2 * D) + ((db ^ vx<D>(vrow)) << 6) + vcol;
-        vf_off[ks][db][1] = 2 * KBYTES + (vrow + 8) * (2 * D) + ((db ^ vx<D>(vrow + 8)) << 6) + vcol;
-      }
-    }
+  }
 
   // ---- staging registers ----------------------------------------------------------------------------
   u32x4 kreg[KCH], vreg[VCH];
@@ -275,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         i32x16 sacc;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-          const i32x4 kf = *reinterpret_cast<const i32x4*>(kbuf + kf_off[kb2][s]);
+          const i32x4 kf = *reinterpret_cast<const i32x4*>(kbuf + kf_base[s] + kb2 * 32 * D);
           if (s == 0) sacc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], cmagic, 0, 0, 0);
           else sacc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], sacc, 0, 0, 0);
         }
@@ -328,10 +278,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           x[kb2][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kb2][i], sc, c1));
-#if !LBFA_DOT2
+#if !LBFA_DOT2 && !LBFA_SUM4
           psum += x[kb2][i];
 #endif
         }
+#if LBFA_SUM4
+      {
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) ps[i & 3] += x[kb2][i];
+        psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+      }
+#endif
 #if LBFA_DOT2
       if constexpr (FP8) {
 #pragma unroll
@@ -385,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         const long pf = (long)(((unsigned long)w1 << 32) | (unsigned long)w0);
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
-          const long vf = *reinterpret_cast<const long*>(vbuf + vf_off[ks][db][0]);
+          const long vf = *reinterpret_cast<const long*>(vbuf + vf_base[ks] + db * 2048);
           acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf, pf, acc_o[db], 0, 0, 0);
         }
       } else {
@@ -394,8 +354,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         for (int e = 0; e < 8; ++e) pf[e] = (_Float16)x[kb2][rb + e];
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
-          const f16x4 lo = lds_read_tr16(vbuf + vf_off[ks][db][0]);
-          const f16x4 hi = lds_read_tr16(vbuf + vf_off[ks][db][1]);
+          const f16x4 lo = lds_read_tr16(vbuf + vf_base[db] + ks * 32 * D);
+          const f16x4 hi = lds_read_tr16(vbuf + vf_base[db] + ks * 32 * D + 16 * D);
           const f16x8 vf = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, acc_o[db], 0, 0, 0);
         }

@@ -34,8 +34,8 @@ namespace lbfa {
 #ifndef LBFA_PRIO
 #define LBFA_PRIO 2  // s_setprio(1) around the PV MFMA section: keeps the matrix pipe fed while other waves exponentiate (+3..6 %)
 #endif
-#ifndef LBFA_SUM4
-#define LBFA_SUM4 0
+#ifndef LBFA_ONES_SUM
+#define LBFA_ONES_SUM 0  // measured: 4 extra MFMAs instead of 32 v_add per lane is 1-3 % SLOWER at D=64 (dependent MFMA chain before the overflow check)
 #endif
 #ifndef LBFA_DOT2
 #define LBFA_DOT2 0
@@ -43,6 +43,22 @@ namespace lbfa {
 #ifndef LBFA_THR
 #define LBFA_THR 8.0f
 #endif
+
+// Row sums of a 64-key tile through the matrix pipe: O_l^T = 1 P^T with an all-ones A operand - every
+// accumulator row is the column sum of P^T over both lane halves.
+template <typename PF>
+__device__ __forceinline__ float ones_rowsum(const PF (&pf)[4]) {
+  if constexpr (std::is_same<PF, f16x8>::value) {
+    const f16x8 ones = f16x8{(_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f,
+                             (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f};
+    f32x16 lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[0], f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[ks], lacc, 0, 0, 0);
+    return lacc[0];
+  } else {
+    return 0.f;
+  }
+}
 
 template <int D, int VT, int OT, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
@@ -55,7 +71,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   constexpr int VBYTES = FP8 ? 64 * D : 128 * D;     // V tile
   constexpr int KCH = KBYTES / (256 * 16);           // 16-B chunks per thread
   constexpr int VCH = VBYTES / (256 * 16);
+#ifdef LBFA_LDS_PAD  // occupancy experiment: pad the LDS footprint to limit workgroups per CU
+  __shared__ __attribute__((aligned(16))) char smem[2 * (KBYTES + VBYTES) + LBFA_LDS_PAD];
+#else
   __shared__ __attribute__((aligned(16))) char smem[2 * (KBYTES + VBYTES)];
+#endif
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -178,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc_o[db][i] = 0.f;
   float m_run = -INFINITY;  // reference max (base-2 domain), identical in both halves of a row
-  float l_run = 0.f;        // running sum over THIS lane's keys only (halves are added in the epilogue)
+  float l_run = 0.f;        // running row sum over all keys seen so far (identical in both halves of a row)
 
   // The int8 MFMA accumulates on top of this constant block (kept in registers for the whole kernel).
   i32x16 cmagic;
@@ -268,44 +288,46 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
           for (int i = 0; i < 16; ++i) acc_o[db][i] *= alpha;
       }
     };
-    float psum;
-    auto exponentiate = [&]() {  // x <- P, in place
+    // Row sums.  l_run always holds the sum over ALL 64 keys of the row (both lane halves).
+    //  * ONES path (lazy fp16 tiles when the matrix pipe has slack, i.e. D = 64): the sum comes from four extra
+    //    MFMAs with an all-ones A operand, O_l^T = 1 P^T - every accumulator row is the column sum of P^T, over
+    //    both halves - instead of 32 v_add_f32 per lane on the saturated VALU;
+    //  * otherwise: fp32 adds of this lane's 32 values, halves combined with one v_permlane32_swap.
+    constexpr bool ONES = LAZY && (LBFA_ONES_SUM != 0) && (D == 64);
+    typedef typename std::conditional<FP8, long, f16x8>::type pfrag_t;
+    pfrag_t pf[4];
+    float tile_sum = 0.f;
+    auto exponentiate = [&]() {  // x <- P in place, pf <- packed P^T fragments, tile_sum <- row sum of the tile
       float c1 = c0 - m_run;  // exact (grid argument above); +inf while m_run = -inf
       if constexpr (FP8) c1 += kFp8Offset;
-      psum = 0.f;
+      float psum = 0.f;
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           x[kb2][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kb2][i], sc, c1));
-#if !LBFA_DOT2 && !LBFA_SUM4
-          psum += x[kb2][i];
-#endif
+          if constexpr (!ONES) psum += x[kb2][i];
         }
-#if LBFA_SUM4
-      {
-        float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2)
+      for (int ks = 0; ks < 4; ++ks) {
+        const int kb2 = ks >> 1, rb = (ks & 1) * 8;
+        if constexpr (FP8) {
+          unsigned w0 = 0, w1 = 0;
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[kb2][rb + 0], x[kb2][rb + 1], w0, false);
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[kb2][rb + 2], x[kb2][rb + 3], w0, true);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[kb2][rb + 4], x[kb2][rb + 5], w1, false);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[kb2][rb + 6], x[kb2][rb + 7], w1, true);
+          pf[ks] = (long)(((unsigned long)w1 << 32) | (unsigned long)w0);
+        } else {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) ps[i & 3] += x[kb2][i];
-        psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+          for (int e = 0; e < 8; ++e) pf[ks][e] = (_Float16)x[kb2][rb + e];
+        }
       }
-#endif
-#if LBFA_DOT2
-      if constexpr (FP8) {
-#pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) psum += x[kb2][i];
-      } else {  // sum of the fp16-rounded P, two per instruction (v_dot2_f32_f16, fp32 accumulate)
-#pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2)
-#pragma unroll
-          for (int i = 0; i < 16; i += 2)
-            psum = __builtin_amdgcn_fdot2(f16x2{(_Float16)x[kb2][i], (_Float16)x[kb2][i + 1]}, f16x2{(_Float16)1.0f, (_Float16)1.0f}, psum, false);
+      if constexpr (ONES) {
+        tile_sum = ones_rowsum(pf);  // sum of the fp16-rounded P over all 64 keys; +inf / NaN if any P overflowed
+      } else {
+        tile_sum = psum;     // this lane's 32 keys; halves are combined below
       }
-#endif
     };
     if constexpr (LAZY) {
       // Any reference within 2^15 of the row max is as good as the max itself (P is fp16/fp32 floating point):
@@ -319,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         compute_scores();
         if (redo) update_reference(0.0f);
         exponentiate();
-        if (redo || !__any(!(psum <= kPLimit))) break;
+        if (redo || !__any(!(tile_sum <= kPLimit))) break;
         redo = true;
       }
     } else {
@@ -327,7 +349,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       update_reference(THR);
       exponentiate();
     }
-    l_run += psum;
+    if constexpr (ONES) l_run += tile_sum;
+    else l_run += half_swap_sum(tile_sum);
 
     // -- O^T += V^T P^T : P^T fragments straight from the score accumulators
 #if LBFA_PRIO & 2
@@ -335,29 +358,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #endif
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int kb2 = ks >> 1, rb = (ks & 1) * 8;
-      if constexpr (FP8) {
-        unsigned w0 = 0, w1 = 0;
-        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[kb2][rb + 0], x[kb2][rb + 1], w0, false);
-        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[kb2][rb + 2], x[kb2][rb + 3], w0, true);
-        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[kb2][rb + 4], x[kb2][rb + 5], w1, false);
-        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[kb2][rb + 6], x[kb2][rb + 7], w1, true);
-        const long pf = (long)(((unsigned long)w1 << 32) | (unsigned long)w0);
 #pragma unroll
-        for (int db = 0; db < DB; ++db) {
+      for (int db = 0; db < DB; ++db) {
+        if constexpr (FP8) {
           const long vf = *reinterpret_cast<const long*>(vbuf + vf_base[ks] + db * 2048);
-          acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf, pf, acc_o[db], 0, 0, 0);
-        }
-      } else {
-        f16x8 pf;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pf[e] = (_Float16)x[kb2][rb + e];
-#pragma unroll
-        for (int db = 0; db < DB; ++db) {
+          acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf, pf[ks], acc_o[db], 0, 0, 0);
+        } else {
           const f16x4 lo = lds_read_tr16(vbuf + vf_base[db] + ks * 32 * D);
           const f16x4 hi = lds_read_tr16(vbuf + vf_base[db] + ks * 32 * D + 16 * D);
           const f16x8 vf = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, acc_o[db], 0, 0, 0);
+          acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ks], acc_o[db], 0, 0, 0);
         }
       }
     }
@@ -403,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   }
 
   // ---- epilogue: O = O^T / l (x v_scale), LSE ------------------------------------------------------------
-  const float l_tot = half_swap_sum(l_run);
+  const float l_tot = l_run;  // already the sum over both lane halves
   const float inv_l = 1.0f / l_tot;
   if (qrow < p.Sq) {
     unsigned short* op = reinterpret_cast<unsigned short*>(p.o) + (int64_t)b * p.ob + (int64_t)h * p.oh + (int64_t)qrow * p.os;

@@ -61,6 +61,15 @@ def _low_bit_attention(q, k, v, *, tensor_layout, is_causal, sm_scale, smooth_k,
     ops, dtype = _check_inputs(q, k, v)
     if tensor_layout not in ("HND", "NHD"):
         raise ValueError(f"Unknown tensor layout: {tensor_layout}")
+    qshape, kshape = ops.shape(q), ops.shape(k)
+    if 0 in qshape:  # nothing to compute: an empty output of the right shape (no launch)
+        o = ops.empty(qshape, dtype, q)
+        if return_lse:
+            hdim = 1 if tensor_layout == "HND" else 2
+            return o, ops.empty((qshape[0], qshape[hdim], qshape[3 - hdim]), ops.float32, q)
+        return o
+    if 0 in kshape:
+        raise ValueError("k/v must hold at least one key (softmax over an empty set is undefined)")
     q, k, v, head_dim_og = _pad_head_dim(ops, q, k, v)
     if sm_scale is None:
         sm_scale = 1.0 / head_dim_og ** 0.5  # ORIGINAL head dim (:309-310)

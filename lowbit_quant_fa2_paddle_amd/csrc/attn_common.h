@@ -46,6 +46,15 @@ __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigne
   return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
 }
 
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [B, E)
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
 constexpr float kFp8Offset = 8.807f;  // csrc/qattn/attn_utils.cuh:30: p = exp2(s - m + 8.807) -> p_max = 448
 constexpr float kMagic = 12582912.0f;  // 1.5 * 2^23: int32 accumulator bits == float(kMagic + s) for |s| < 2^22
 constexpr int kMagicBits = 0x4B400000;

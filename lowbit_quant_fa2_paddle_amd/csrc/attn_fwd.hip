@@ -34,11 +34,11 @@ namespace lbfa {
 #ifndef LBFA_PRIO
 #define LBFA_PRIO 2  // s_setprio(1) around the PV MFMA section: keeps the matrix pipe fed while other waves exponentiate (+3..6 %)
 #endif
+#ifndef LBFA_VPRE
+#define LBFA_VPRE(D) 0  // measured: prefetch distances 2..8 change nothing beyond noise (other waves already hide the LDS latency)
+#endif
 #ifndef LBFA_ONES_SUM
 #define LBFA_ONES_SUM 0  // measured: 4 extra MFMAs instead of 32 v_add per lane is 1-3 % SLOWER at D=64 (dependent MFMA chain before the overflow check)
-#endif
-#ifndef LBFA_DOT2
-#define LBFA_DOT2 0
 #endif
 #ifndef LBFA_THR
 #define LBFA_THR 8.0f
@@ -329,6 +329,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         tile_sum = psum;     // this lane's 32 keys; halves are combined below
       }
     };
+    // V^T fragments do not depend on P: request the first NPRE of them now, so they land while the VALU
+    // exponentiates, and keep requesting NPRE MFMAs ahead inside the PV loop (with only 2-3 waves per SIMD an
+    // LDS read issued right before its MFMA costs that MFMA the full LDS latency).
+    constexpr int NMF = 4 * DB;                       // PV MFMAs of the tile, index = ks * DB + db
+    constexpr int NPRE = FP8 ? 0 : LBFA_VPRE(D);      // software prefetch distance (fp16 V)
+    f16x4 vlo[NMF], vhi[NMF];                          // fully unrolled: only NPRE+1 of them are live at a time
+    auto v_request = [&](auto idx_tag) {
+      constexpr int idx = decltype(idx_tag)::value;
+      constexpr int ks = idx / DB, db = idx % DB;
+      if constexpr (!FP8) {
+        vlo[idx] = lds_read_tr16(vbuf + vf_base[db] + ks * 32 * D);
+        vhi[idx] = lds_read_tr16(vbuf + vf_base[db] + ks * 32 * D + 16 * D);
+      }
+    };
+    static_for<0, NPRE>([&](auto i) { v_request(i); });
+
     if constexpr (LAZY) {
       // Any reference within 2^15 of the row max is as good as the max itself (P is fp16/fp32 floating point):
       // exponentiate against the current reference and look at the row sum, which bounds every P from above.
@@ -356,21 +372,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #if LBFA_PRIO & 2
     __builtin_amdgcn_s_setprio(1);
 #endif
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-      for (int db = 0; db < DB; ++db) {
-        if constexpr (FP8) {
-          const long vf = *reinterpret_cast<const long*>(vbuf + vf_base[ks] + db * 2048);
-          acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf, pf[ks], acc_o[db], 0, 0, 0);
-        } else {
-          const f16x4 lo = lds_read_tr16(vbuf + vf_base[db] + ks * 32 * D);
-          const f16x4 hi = lds_read_tr16(vbuf + vf_base[db] + ks * 32 * D + 16 * D);
-          const f16x8 vf = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ks], acc_o[db], 0, 0, 0);
-        }
+    static_for<0, NMF>([&](auto i) {
+      constexpr int idx = decltype(i)::value;
+      constexpr int ks = idx / DB, db = idx % DB;
+      if constexpr (FP8) {
+        const long vf = *reinterpret_cast<const long*>(vbuf + vf_base[ks] + db * 2048);
+        acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf, pf[ks], acc_o[db], 0, 0, 0);
+      } else {
+        if constexpr (idx + NPRE < NMF) v_request(std::integral_constant<int, idx + NPRE>{});
+        const f16x8 vf = f16x8{vlo[idx][0], vlo[idx][1], vlo[idx][2], vlo[idx][3], vhi[idx][0], vhi[idx][1], vhi[idx][2], vhi[idx][3]};
+        acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ks], acc_o[db], 0, 0, 0);
       }
-    }
+    });
 #if LBFA_PRIO & 2
     __builtin_amdgcn_s_setprio(0);
 #endif

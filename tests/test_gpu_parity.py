@@ -336,3 +336,17 @@ def test_quant_division_exceptional_divisor(oracle, dev):
     assert np.all(rs.view(np.uint32) == 0x3C7FFFFF), "test did not hit the exceptional divisor"
     assert np.array_equal(scale.cpu().numpy().view(np.uint32), rs.view(np.uint32))
     assert np.array_equal(codes.cpu().numpy(), rc)
+
+
+def test_empty_inputs(dev):
+    """Edge cases around emptiness: no queries -> empty output without a launch; no keys -> ValueError."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    k = torch.randn(1, 2, 64, 64, device=dev).half()
+    q0 = torch.empty(1, 2, 0, 64, device=dev, dtype=torch.float16)
+    o, lse = lb.lowbit_fa_qk_int8_pv_fp16_triton(q0, k, k, return_lse=True)
+    assert tuple(o.shape) == (1, 2, 0, 64) and tuple(lse.shape) == (1, 2, 0)
+    b0 = torch.empty(0, 2, 64, 64, device=dev, dtype=torch.float16)
+    assert tuple(lb.lowbit_fa_qk_int8_pv_fp8_cuda(b0, b0, b0).shape) == (0, 2, 64, 64)
+    k0 = torch.empty(1, 2, 0, 64, device=dev, dtype=torch.float16)
+    with pytest.raises(ValueError, match="at least one key"):
+        lb.lowbit_fa_qk_int8_pv_fp16_triton(k, k0, k0)

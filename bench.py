@@ -93,7 +93,6 @@ def main():
 
     import torch
     import lowbit_quant_fa2_paddle_amd as lb
-    from lowbit_quant_fa2_paddle_amd import attn_qk_int8_per_block as attn_mod
     from lowbit_quant_fa2_paddle_amd import _lib
     _lib.load()  # fail loudly when the HIP library is missing
 
@@ -130,11 +129,16 @@ def main():
     def step():
         return fn(q, k, v, tensor_layout=layout, is_causal=causal, **extra)
 
-    # per-launch timing of the dominant kernel with HIP events on the launch stream (torch's current stream)
+    # per-launch timing of the dominant kernel with HIP events recorded by the library itself on the launch stream
+    # (lbfa_profile_next_attn: the next fused-attention launch is bracketed by the two events), inside the timed region
+    lib = _lib.load()
     attn_events = []
 
-    def hook(start, stop):
-        attn_events.append((start, stop))
+    def arm_kernel_timer():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); e1.record()  # materialise the hipEvent handles (re-recorded by the library)
+        lib.lbfa_profile_next_attn(e0.cuda_event, e1.cuda_event)
+        attn_events.append((e0, e1))
 
     def barrier():
         if distributed:
@@ -144,13 +148,12 @@ def main():
     for _ in range(args.warmup):
         o = step()
     barrier()
-    attn_mod.EVENT_HOOK = hook
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        arm_kernel_timer()
         o = step()
     barrier()
     t1 = time.perf_counter()
-    attn_mod.EVENT_HOOK = None
     elapsed = t1 - t0
     if distributed:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)

@@ -127,6 +127,34 @@ int lbfa_attn_fwd(const int8_t* q, const int8_t* k, const void* v, int v_dtype, 
                   const int64_t strides_q[3], const int64_t strides_k[3], const int64_t strides_v[3],
                   const int64_t strides_o[3], int is_causal, void* stream);
 
+/*
+ * Profiling aid: the NEXT fused-attention launch made on this thread (by lbfa_attn_fwd or lbfa_forward) is bracketed by
+ * hipEventRecord(start_event) / hipEventRecord(stop_event) on its stream; one-shot.  Both are hipEvent_t passed
+ * as void* (NULL clears).  Used by bench.py to time the dominant kernel inside the timed region.
+ */
+int lbfa_profile_next_attn(void* start_event, void* stop_event);
+
+/*
+ * The whole operator in ONE call: smooth-K mean, per-block quantisation of Q and K, (fp8: per-channel V
+ * quantisation,) fused attention and the LSE fix-up - the body of `sageattn_qk_int8_pv_fp16_triton`
+ * (src/core.py:292-350), of `sageattn_qk_int4_pv_fp16_triton` (q_qmax / k_qmax = 7) and of
+ * `sageattn_qk_int8_pv_fp8_cuda` (pv_fp8 = 1) after their argument checks and head-dim padding.  Same kernels
+ * and results as calling the entry points above one by one (the host front end uses this one to keep the
+ * per-call host overhead at one FFI call and one workspace allocation).
+ *   q, k, v : fp16/bf16 (dtype), strides in elements {batch, head, seq}; o same dtype, strides_o.
+ *   lse     : NULL, or [B,Hq,Sq] fp32 receiving the NATURAL-log LSE incl. the smooth-K correction
+ *             (lse2 / 1.44269504 + (q . km) * sm_scale, src/core.py:344-350).
+ *   workspace: >= lbfa_forward_workspace_bytes(...) bytes, 16-byte aligned, caller-owned scratch (int8 codes,
+ *             scales, km, partial sums, fp8 V); contents are undefined afterwards.
+ *   sm_scale: softmax scale (1/sqrt(original head_dim) by default on the host side); q_qmax/k_qmax in {127, 7}.
+ */
+size_t lbfa_forward_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int pv_fp8, int smooth_k, int return_lse);
+int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o, float* lse, void* workspace,
+                 size_t workspace_bytes, int B, int Hq, int Hkv, int Sq, int Sk, int D,
+                 const int64_t strides_q[3], const int64_t strides_k[3], const int64_t strides_v[3],
+                 const int64_t strides_o[3], float sm_scale, int q_qmax, int k_qmax, int pv_fp8, int is_causal,
+                 int smooth_k, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

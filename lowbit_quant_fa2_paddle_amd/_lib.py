@@ -35,6 +35,12 @@ SIGNATURES = {
     "lbfa_attn_fwd": (_ci, [_vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci,
                             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), _ci, _vp]),
+    "lbfa_profile_next_attn": (_ci, [_vp, _vp]),
+    "lbfa_forward_workspace_bytes": (_sz, [_ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci]),
+    "lbfa_forward": (_ci, [_vp, _vp, _vp, _ci, _vp, _vp, _vp, _sz, _ci, _ci, _ci, _ci, _ci, _ci,
+                           ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                           ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                           _cf, _ci, _ci, _ci, _ci, _ci, _vp]),
 }
 
 _lock = threading.Lock()

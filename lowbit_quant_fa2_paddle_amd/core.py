@@ -15,8 +15,7 @@ from __future__ import annotations
 import warnings
 from typing import Any, Optional
 
-from . import attn_qk_int8_per_block as _attn
-from . import quant as _quant
+from . import _lib
 from . import quant_per_block as _qpb
 from ._tensor import ops_for
 
@@ -73,28 +72,31 @@ def _low_bit_attention(q, k, v, *, tensor_layout, is_causal, sm_scale, smooth_k,
     q, k, v, head_dim_og = _pad_head_dim(ops, q, k, v)
     if sm_scale is None:
         sm_scale = 1.0 / head_dim_og ** 0.5  # ORIGINAL head dim (:309-310)
-    km = _qpb.mean_seq(k, tensor_layout) if smooth_k else None  # :292-293
-    # Q: sm_scale*log2e folded in (quant_per_block.py:226).  With smooth_k + return_lse the same launch
-    # also produces lse_correction = q . km (:294-304).
-    want_corr = smooth_k and return_lse
-    qres = _qpb.quantize(q, sm_scale=sm_scale * _LOG2E, qmax=q_qmax, blk=128, tensor_layout=tensor_layout,
-                         rowdot_vec=km if want_corr else None)
-    q_int8, q_scale = qres[0], qres[1]
-    lse_correction = qres[2] if want_corr else None
-    k_int8, k_scale = _qpb.quantize(k, sm_scale=1.0, qmax=k_qmax, blk=64, tensor_layout=tensor_layout, mean=km)
-    if pv == "fp8":
-        v_in, v_scale, _ = _quant.per_channel_fp8(v, tensor_layout=tensor_layout)
-    else:
-        v_in, v_scale = v, None  # bf16 V is converted to fp16 inside the kernel (replaces :307-308)
-    o, lse = _attn.forward(q_int8, k_int8, v_in, q_scale, k_scale, tensor_layout=tensor_layout, output_dtype=dtype,
-                           return_lse=return_lse, is_causal=is_causal, v_scale=v_scale)
+    # mean_S(K), quantisation of Q and K (fp8: of V), attention and the LSE fix-up (:292-350) run inside ONE C-ABI
+    # call on one caller-owned workspace: lbfa_forward == lbfa_mean_seq + 2 x lbfa_quant_per_block
+    # (+ lbfa_quant_v_fp8) + lbfa_attn_fwd, which stay available (and tested) as separate entry points.
+    lib = _lib.load()
+    qshape, kshape = ops.shape(q), ops.shape(k)
+    (B, Hq, Sq), q3 = _qpb._bhs(qshape, ops.strides(q), tensor_layout)
+    (_, Hkv, Sk), k3 = _qpb._bhs(kshape, ops.strides(k), tensor_layout)
+    (_, _, _), v3 = _qpb._bhs(ops.shape(v), ops.strides(v), tensor_layout)
+    D = qshape[3]
+    if is_causal and Sq != Sk:
+        raise AssertionError("qo_len and kv_len must be equal for causal attention")  # causal forward :389
+    o = ops.empty(qshape, dtype, q)
+    (_, _, _), o3 = _qpb._bhs(qshape, ops.strides(o), tensor_layout)
+    lse = ops.empty((B, Hq, Sq), ops.float32, q) if return_lse else None
+    fp8 = 1 if pv == "fp8" else 0
+    ws_bytes = lib.lbfa_forward_workspace_bytes(B, Hq, Hkv, Sq, Sk, D, fp8, 1 if smooth_k else 0, 1 if return_lse else 0)
+    ws = ops.empty((ws_bytes,), ops.uint8, q)
+    with ops.device_guard(q):
+        _lib.check(lib.lbfa_forward(ops.ptr(q), ops.ptr(k), ops.ptr(v), ops.dtype_code(q), ops.ptr(o),
+                                    ops.ptr(lse) if return_lse else None, ops.ptr(ws), ws_bytes,
+                                    B, Hq, Hkv, Sq, Sk, D, _lib.strides3(q3), _lib.strides3(k3), _lib.strides3(v3),
+                                    _lib.strides3(o3), float(sm_scale), int(q_qmax), int(k_qmax), fp8,
+                                    1 if is_causal else 0, 1 if smooth_k else 0, ops.stream(q)), lib)
     o = o[..., :head_dim_og]
-    if return_lse:
-        lse = lse / _LOG2E
-        if smooth_k:
-            lse = lse + lse_correction * sm_scale
-        return o, lse
-    return o
+    return (o, lse) if return_lse else o
 
 
 # ------------------------------------------------------------------------------------------------------

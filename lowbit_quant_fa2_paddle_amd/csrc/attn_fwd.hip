@@ -451,7 +451,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     if (p.lse != nullptr && hh == 0) {
       float ls = log2f(l_tot) + m_run;  // base-2 domain (attn_qk_int8_per_block.py:164-167)
       if constexpr (FP8) ls -= kFp8Offset;  // qk_int_sv_f8_cuda.cu:689
-      p.lse[((int64_t)b * p.Hq + h) * p.Sq + qrow] = ls;
+      const int64_t li = ((int64_t)b * p.Hq + h) * p.Sq + qrow;
+      ls *= p.lse_scale;
+      if (p.lse_corr != nullptr) ls += p.lse_corr[li] * p.lse_corr_scale;
+      p.lse[li] = ls;
     }
   }
 }

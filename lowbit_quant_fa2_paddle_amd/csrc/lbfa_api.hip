@@ -20,6 +20,10 @@ hipError_t launch_attn_fwd(const AttnParams& p, int D, int v_dtype, int o_dtype,
 
 namespace {
 thread_local char g_err[512] = "";
+thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;  // one-shot, see lbfa_profile_next_attn
+
+// launches the fused attention kernel, bracketed by the caller's events when a profile request is pending
+hipError_t launch_attention(const lbfa::AttnParams& p, int D, int v_dtype, int o_dtype, int causal, hipStream_t stream);
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -36,7 +40,24 @@ bool dims_ok(int B, int H, int S, int D) { return B > 0 && H > 0 && S > 0 && (D 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 }  // namespace
 
+namespace {
+hipError_t launch_attention(const lbfa::AttnParams& p, int D, int v_dtype, int o_dtype, int causal, hipStream_t stream) {
+  const hipEvent_t e0 = g_prof_start, e1 = g_prof_stop;
+  g_prof_start = g_prof_stop = nullptr;
+  if (e0) (void)hipEventRecord(e0, stream);
+  const hipError_t err = lbfa::launch_attn_fwd(p, D, v_dtype, o_dtype, causal, stream);
+  if (e1) (void)hipEventRecord(e1, stream);
+  return err;
+}
+}  // namespace
+
 extern "C" {
+
+int lbfa_profile_next_attn(void* start_event, void* stop_event) {
+  g_prof_start = (hipEvent_t)start_event;
+  g_prof_stop = (hipEvent_t)stop_event;
+  return LBFA_OK;
+}
 
 int lbfa_version(void) { return LBFA_VERSION; }
 
@@ -162,9 +183,120 @@ int lbfa_attn_fwd(const int8_t* q, const int8_t* k, const void* v, int v_dtype, 
   p.nQ = (Sq + LBFA_BLKQ - 1) / LBFA_BLKQ;
   p.nK = (Sk + LBFA_BLKK - 1) / LBFA_BLKK;
   p.group = Hq / Hkv;
+  p.lse_corr = nullptr;
+  p.lse_scale = 1.0f;
+  p.lse_corr_scale = 0.0f;
   if ((int64_t)B * Hq * p.nQ > 0x7fffffffLL) return fail(LBFA_EINVAL, "lbfa_attn_fwd: grid too large");
   g_err[0] = 0;
-  return check_hip(lbfa::launch_attn_fwd(p, D, v_dtype, o_dtype, is_causal ? 1 : 0, (hipStream_t)stream), "lbfa_attn_fwd launch");
+  return check_hip(launch_attention(p, D, v_dtype, o_dtype, is_causal ? 1 : 0, (hipStream_t)stream), "lbfa_attn_fwd launch");
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// whole operator in one call
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+struct FwdLayout {
+  size_t km, part, q8, k8, qs, ks, corr, v8, vs, total;
+};
+FwdLayout fwd_layout(int B, int Hq, int Hkv, int Sq, int Sk, int D, int pv_fp8, int want_corr) {
+  FwdLayout L;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t at = o; o += align256(n); return at; };
+  L.km = take((size_t)B * Hkv * D * 2);
+  L.part = take(lbfa_mean_seq_workspace_bytes(B, Hkv, Sk, D));
+  L.q8 = take((size_t)B * Hq * Sq * D);
+  L.k8 = take((size_t)B * Hkv * Sk * D);
+  L.qs = take((size_t)B * Hq * ((Sq + LBFA_BLKQ - 1) / LBFA_BLKQ) * 4);
+  L.ks = take((size_t)B * Hkv * ((Sk + LBFA_BLKK - 1) / LBFA_BLKK) * 4);
+  L.corr = take(want_corr ? (size_t)B * Hq * Sq * 4 : 0);
+  L.v8 = take(pv_fp8 ? lbfa_v_fp8_bytes(B, Hkv, Sk, D) : 0);
+  L.vs = take(pv_fp8 ? (size_t)B * Hkv * D * 4 : 0);
+  L.total = o;
+  return L;
+}
+}  // namespace
+
+size_t lbfa_forward_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int pv_fp8, int smooth_k, int return_lse) {
+  if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Sk <= 0 || D <= 0) return 0;
+  return fwd_layout(B, Hq, Hkv, Sq, Sk, D, pv_fp8, smooth_k && return_lse).total;
+}
+
+int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o, float* lse, void* workspace,
+                 size_t workspace_bytes, int B, int Hq, int Hkv, int Sq, int Sk, int D,
+                 const int64_t strides_q[3], const int64_t strides_k[3], const int64_t strides_v[3],
+                 const int64_t strides_o[3], float sm_scale, int q_qmax, int k_qmax, int pv_fp8, int is_causal,
+                 int smooth_k, void* stream) {
+  if (!q || !k || !v || !o || !workspace || !strides_q || !strides_k || !strides_v || !strides_o)
+    return fail(LBFA_EINVAL, "lbfa_forward: null pointer");
+  if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Sk <= 0) return fail(LBFA_EINVAL, "lbfa_forward: empty tensor");
+  if (D != 64 && D != 128) return fail(LBFA_EINVAL, "Unsupported head_dim: %d", D);
+  if (Hq % Hkv != 0) return fail(LBFA_EINVAL, "num_qo_heads (%d) must be divisible by num_kv_heads (%d)", Hq, Hkv);
+  const int want_lse = lse != nullptr, want_corr = want_lse && smooth_k;
+  const FwdLayout L = fwd_layout(B, Hq, Hkv, Sq, Sk, D, pv_fp8, want_corr);
+  if (workspace_bytes < L.total) return fail(LBFA_EINVAL, "lbfa_forward: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+  if (!aligned16(workspace)) return fail(LBFA_EINVAL, "lbfa_forward: workspace must be 16-byte aligned");
+  char* ws = (char*)workspace;
+  void* km = smooth_k ? (void*)(ws + L.km) : nullptr;
+  int8_t* q8 = (int8_t*)(ws + L.q8);
+  int8_t* k8 = (int8_t*)(ws + L.k8);
+  float* qs = (float*)(ws + L.qs);
+  float* ks = (float*)(ws + L.ks);
+  float* corr = want_corr ? (float*)(ws + L.corr) : nullptr;
+  const int64_t sq8[3] = {(int64_t)Hq * Sq * D, (int64_t)Sq * D, D};     // int8 codes: contiguous [B,H,S,D]
+  const int64_t sk8[3] = {(int64_t)Hkv * Sk * D, (int64_t)Sk * D, D};
+  int st;
+  if (smooth_k) {
+    st = lbfa_mean_seq(k, dtype, km, ws + L.part, lbfa_mean_seq_workspace_bytes(B, Hkv, Sk, D), B, Hkv, Sk, D, strides_k, stream);
+    if (st) return st;
+  }
+  // Q: sm_scale * log2(e) folded into the codes' scale (src/triton/quant_per_block.py:226); lse_correction = q . km
+  st = lbfa_quant_per_block(q, dtype, nullptr, 1, q8, qs, sm_scale * 1.44269504f, q_qmax, LBFA_BLKQ, B, Hq, Sq, D, strides_q, sq8,
+                            want_corr ? km : nullptr, Hq / Hkv, corr, stream);
+  if (st) return st;
+  st = lbfa_quant_per_block(k, dtype, km, 1, k8, ks, 1.0f, k_qmax, LBFA_BLKK, B, Hkv, Sk, D, strides_k, sk8, nullptr, 1, nullptr, stream);
+  if (st) return st;
+  const void* v_in = v;
+  int v_dtype = dtype;
+  const float* v_scale = nullptr;
+  if (pv_fp8) {
+    st = lbfa_quant_v_fp8(v, dtype, (uint8_t*)(ws + L.v8), (float*)(ws + L.vs), B, Hkv, Sk, D, strides_v, stream);
+    if (st) return st;
+    v_in = ws + L.v8;
+    v_dtype = LBFA_E4M3;
+    v_scale = (const float*)(ws + L.vs);
+  }
+  // attention (same checks as lbfa_attn_fwd), with the LSE fix-up of src/core.py:344-350 fused into the epilogue
+  if (is_causal && Sq != Sk) return fail(LBFA_EINVAL, "qo_len and kv_len must be equal for causal attention");
+  if (v_dtype != LBFA_E4M3 && (!aligned16(v) || (strides_v[0] | strides_v[1] | strides_v[2]) % 8 != 0))
+    return fail(LBFA_EINVAL, "lbfa_forward: v must be 16-byte aligned with strides that are multiples of 8 elements");
+  if ((reinterpret_cast<uintptr_t>(o) & 7u) || (strides_o[0] | strides_o[1] | strides_o[2]) % 4 != 0)
+    return fail(LBFA_EINVAL, "lbfa_forward: o must be 8-byte aligned with strides that are multiples of 4 elements");
+  {
+    const int64_t lim = 0x7fffffffLL;
+    const int64_t vwin = v_dtype == LBFA_E4M3 ? ((int64_t)Sk + 2 * LBFA_BLKK) * D : 2 * (((int64_t)Sk + 2 * LBFA_BLKK) * strides_v[2] + D);
+    if (((int64_t)Sq + LBFA_BLKQ) * D + D > lim || ((int64_t)Sk + 2 * LBFA_BLKK) * D + D > lim || vwin > lim)
+      return fail(LBFA_EINVAL, "lbfa_forward: per-(batch,head) operand window exceeds 2 GiB");
+  }
+  lbfa::AttnParams p;
+  p.q = q8; p.k = k8; p.v = v_in; p.o = o; p.lse = lse;
+  p.q_scale = qs; p.k_scale = ks; p.v_scale = v_scale;
+  p.qb = sq8[0]; p.qh = sq8[1]; p.qs = sq8[2];
+  p.kb = sk8[0]; p.kh = sk8[1]; p.ks = sk8[2];
+  if (v_dtype != LBFA_E4M3) { p.vb = strides_v[0]; p.vh = strides_v[1]; p.vs = strides_v[2]; }
+  else { p.vb = p.vh = p.vs = 0; }
+  p.ob = strides_o[0]; p.oh = strides_o[1]; p.os = strides_o[2];
+  p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Sq = Sq; p.Sk = Sk;
+  p.nQ = (Sq + LBFA_BLKQ - 1) / LBFA_BLKQ;
+  p.nK = (Sk + LBFA_BLKK - 1) / LBFA_BLKK;
+  p.group = Hq / Hkv;
+  p.lse_corr = corr;
+  p.lse_scale = 1.0f / 1.44269504f;   // natural-log LSE (src/core.py:347)
+  p.lse_corr_scale = sm_scale;
+  if ((int64_t)B * Hq * p.nQ > 0x7fffffffLL) return fail(LBFA_EINVAL, "lbfa_forward: grid too large");
+  g_err[0] = 0;
+  return check_hip(launch_attention(p, D, v_dtype, dtype, is_causal ? 1 : 0, (hipStream_t)stream), "lbfa_forward launch");
 }
 
 }  // extern "C"

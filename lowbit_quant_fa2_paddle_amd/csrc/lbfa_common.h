@@ -90,6 +90,10 @@ struct AttnParams {
   const float* v_scale;
   int64_t qb, qh, qs, kb, kh, ks, vb, vh, vs, ob, oh, os;
   int B, Hq, Hkv, Sq, Sk, nQ, nK, group;
+  // LSE post-processing (src/core.py:344-350): lse_out = (log2(l) + m) * lse_scale + lse_corr[b,h,s] * lse_corr_scale.
+  // lbfa_attn_fwd uses (1, null): the raw base-2 value the reference kernel stores.
+  const float* lse_corr;
+  float lse_scale, lse_corr_scale;
 };
 
 }  // namespace lbfa

@@ -350,3 +350,29 @@ def test_empty_inputs(dev):
     k0 = torch.empty(1, 2, 0, 64, device=dev, dtype=torch.float16)
     with pytest.raises(ValueError, match="at least one key"):
         lb.lowbit_fa_qk_int8_pv_fp16_triton(k, k0, k0)
+
+
+@pytest.mark.parametrize("layout,causal,pv", [("HND", False, "fp16"), ("NHD", True, "fp16"), ("HND", True, "fp8")])
+def test_one_call_forward_equals_modular_entry_points(oracle, dev, layout, causal, pv):
+    """lbfa_forward (what the operators call) == lbfa_mean_seq + 2 x lbfa_quant_per_block (+ lbfa_quant_v_fp8)
+    + lbfa_attn_fwd composed on the host: O bit-identical, LSE (fix-up fused in the kernel epilogue vs torch ops) to 1e-6."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    from lowbit_quant_fa2_paddle_amd import attn_qk_int8_per_block as attn, quant, quant_per_block as qpb
+    B, H, Hkv, S, D = 2, 4, 2, 320, 128
+    q, k, v = oracle.make_inputs(B, H, S, D, seed=41, layout=layout, Hkv=Hkv, k_bias=0.4)
+    tq, tk, tv = (_t(a, "fp16", dev) for a in (q, k, v))
+    fn = lb.lowbit_fa_qk_int8_pv_fp16_triton if pv == "fp16" else lb.lowbit_fa_qk_int8_pv_fp8_cuda
+    o, lse = fn(tq, tk, tv, tensor_layout=layout, is_causal=causal, return_lse=True)
+    sm_scale = D ** -0.5
+    km = qpb.mean_seq(tk, layout)
+    q8, qs, corr = qpb.quantize(tq, sm_scale=sm_scale * 1.44269504, qmax=127, blk=128, tensor_layout=layout, rowdot_vec=km)
+    k8, ks = qpb.quantize(tk, sm_scale=1.0, qmax=127, blk=64, tensor_layout=layout, mean=km)
+    if pv == "fp8":
+        vin, vs, _ = quant.per_channel_fp8(tv, tensor_layout=layout)
+    else:
+        vin, vs = tv, None
+    o2, lse2 = attn.forward(q8, k8, vin, qs, ks, tensor_layout=layout, output_dtype=torch.float16, return_lse=True,
+                            is_causal=causal, v_scale=vs)
+    assert torch.equal(o, o2)
+    lse_host = lse2 / 1.44269504 + corr * sm_scale
+    assert float((lse - lse_host).abs().max()) <= 1e-5

@@ -155,6 +155,45 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
                  const int64_t strides_o[3], float sm_scale, int q_qmax, int k_qmax, int pv_fp8, int is_causal,
                  int smooth_k, void* stream);
 
+/*
+ * Packed variable-length batches (reference: `sageattn_varlen`, src/core.py:356-491).
+ *   q [total_q, Hq, D], k / v [total_k, Hkv, D]; sequence b owns tokens [cu_seqlens[b], cu_seqlens[b+1]);
+ *   cu_seqlens_* are int32 device arrays of B + 1 entries; strides are in elements {head, token}.
+ *   Quantisation blocks (128 query / 64 key rows) restart at the start of every sequence.
+ *
+ * lbfa_quant_per_block_varlen replaces one launch of the varlen `quant_per_block_int8_kernel`
+ * (src/triton/quant_per_block_varlen.py:22-72,107-141): scale is [sum_b ceil(len_b/blk), H] with
+ * cu_seqlens_scale[b] = number of blocks before sequence b (:92-106).  `mean` (NULL or [H/mean_group, D]) is ONE
+ * vector per head shared by all sequences - the reference smooths with k.mean(dim=0) over the packed tokens
+ * (src/core.py:452-454) - and is subtracted in the storage dtype as in the dense quantiser.
+ *
+ * lbfa_attn_fwd_varlen replaces `_attn_fwd` of src/triton/attn_qk_int8_block_varlen.py:94-197 and its causal twin
+ * (attn_qk_int8_per_block_causal_varlen.py) with the same scale layout; causal assumes len_q == len_k per sequence.
+ * No LSE (the reference returns none).  A sequence with len_k == 0 gets zeros.
+ *
+ * lbfa_forward_varlen = the whole operator in one call (mean over all tokens, both quantisers, attention) on a
+ * caller-owned workspace of lbfa_forward_varlen_workspace_bytes(...) bytes; internally the scales use a padded
+ * [B, H, max_blocks] layout, so no cu_seqlens_scale tables are needed.
+ */
+int lbfa_quant_per_block_varlen(const void* x, int dtype, const void* mean, int mean_group, int8_t* out, float* scale,
+                                const int32_t* cu_seqlens, const int32_t* cu_seqlens_scale, float sm_scale, int qmax,
+                                int blk, int B, int max_seqlen, int H, int D, const int64_t strides_x[2],
+                                const int64_t strides_out[2], void* stream);
+int lbfa_attn_fwd_varlen(const int8_t* q, const int8_t* k, const void* v, int v_dtype, void* o, int o_dtype,
+                         const float* q_scale, const float* k_scale, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                         const int32_t* cu_seqlens_q_scale, const int32_t* cu_seqlens_k_scale,
+                         int B, int Hq, int Hkv, int max_seqlen_q, int max_seqlen_k, int D,
+                         const int64_t strides_q[2], const int64_t strides_k[2], const int64_t strides_v[2],
+                         const int64_t strides_o[2], int is_causal, void* stream);
+size_t lbfa_forward_varlen_workspace_bytes(int B, int Hq, int Hkv, int total_q, int total_k, int max_seqlen_q,
+                                           int max_seqlen_k, int D);
+int lbfa_forward_varlen(const void* q, const void* k, const void* v, int dtype, void* o,
+                        const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, void* workspace, size_t workspace_bytes,
+                        int B, int Hq, int Hkv, int total_q, int total_k, int max_seqlen_q, int max_seqlen_k, int D,
+                        const int64_t strides_q[2], const int64_t strides_k[2], const int64_t strides_v[2],
+                        const int64_t strides_o[2], float sm_scale, int q_qmax, int k_qmax, int is_causal, int smooth_k,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

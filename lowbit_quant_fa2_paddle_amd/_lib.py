@@ -19,6 +19,7 @@ LBFA_OK, LBFA_EINVAL, LBFA_ELAUNCH = 0, 1, 2
 BLKQ, BLKK = 128, 64
 
 _i64x3 = ctypes.c_int64 * 3
+_i64x2 = ctypes.c_int64 * 2
 _vp, _ci, _cf, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 
 # name -> (restype, argtypes); must list every symbol declared in include/lowbit_fa.h
@@ -41,6 +42,18 @@ SIGNATURES = {
                            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                            _cf, _ci, _ci, _ci, _ci, _ci, _vp]),
+    "lbfa_quant_per_block_varlen": (_ci, [_vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _cf, _ci, _ci, _ci, _ci, _ci, _ci,
+                                          ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), _vp]),
+    "lbfa_attn_fwd_varlen": (_ci, [_vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _ci, _ci, _ci, _ci, _ci, _ci,
+                                   ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                   ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), _ci, _vp]),
+    "lbfa_forward_varlen_workspace_bytes": (_sz, [_ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci]),
+    "lbfa_forward_varlen": (_ci, [_vp, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _sz,
+                                  _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci,
+                                  ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                  ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                  _cf, _ci, _ci, _ci, _ci, _vp]),
 }
 
 _lock = threading.Lock()
@@ -74,6 +87,10 @@ def load():
 
 def strides3(s):
     return _i64x3(int(s[0]), int(s[1]), int(s[2]))
+
+
+def strides2(s):
+    return _i64x2(int(s[0]), int(s[1]))
 
 
 def check(status: int, lib=None):

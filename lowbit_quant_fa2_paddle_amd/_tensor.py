@@ -64,6 +64,14 @@ class TorchOps:
     def cat0(self, ts):
         return self.torch.cat(ts, dim=0)
 
+    def as_int32(self, t):
+        """cu_seqlens may be int32 or int64 (src/core.py:418); the C ABI takes contiguous int32."""
+        return t.to(self.torch.int32).contiguous()
+
+    def cumsum0_pad(self, t):
+        """[0, cumsum(t)] as int32 (quant_per_block_varlen.py:95-100)."""
+        return self.torch.nn.functional.pad(self.torch.cumsum(t, dim=0), (1, 0), value=0).to(self.torch.int32)
+
 
 class PaddleOps:  # pragma: no cover - Paddle is absent from the build image; same primitives, untested here
     name = "paddle"
@@ -114,6 +122,12 @@ class PaddleOps:  # pragma: no cover - Paddle is absent from the build image; sa
 
     def cat0(self, ts):
         return self.paddle.concat(ts, axis=0)
+
+    def as_int32(self, t):
+        return t.astype(self.paddle.int32).contiguous()
+
+    def cumsum0_pad(self, t):
+        return self.paddle.concat([self.paddle.zeros([1], dtype=t.dtype), self.paddle.cumsum(t, axis=0)]).astype(self.paddle.int32)
 
 
 def device2str(type=None, index=None, *, device=None):

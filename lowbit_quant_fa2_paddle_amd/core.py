@@ -175,22 +175,39 @@ def sageattn(q, k, v, tensor_layout: str = "HND", is_causal: bool = False, sm_sc
 
 def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_seqlen_k: int,
                     is_causal: bool = False, sm_scale: Optional[float] = None, smooth_k: bool = True, **kwargs: Any):
-    """Variable-length batch (reference: src/core.py:356-491): q [sum_q, Hq, D], k/v [sum_k, Hkv, D], cu_seqlens
-    int32 [B+1].  Each sequence is an independent attention problem (smooth-K mean is per sequence in the
-    reference too, quant_per_block_varlen.py); sequences are dispatched one by one as NHD batches of 1 onto the
-    dense kernel and written into one packed output."""
-    ops = ops_for(q)
-    cq = [int(x) for x in cu_seqlens_q.tolist()]
-    ck = [int(x) for x in cu_seqlens_k.tolist()]
-    if len(cq) != len(ck):
-        raise ValueError("cu_seqlens_q and cu_seqlens_k must have the same length")
-    outs = []
-    for i in range(len(cq) - 1):
-        qi, ki, vi = q[cq[i]:cq[i + 1]], k[ck[i]:ck[i + 1]], v[ck[i]:ck[i + 1]]
-        oi = sageattn_qk_int8_pv_fp16_triton(qi[None], ki[None], vi[None], tensor_layout="NHD", is_causal=is_causal,
-                                             sm_scale=sm_scale, smooth_k=smooth_k)
-        outs.append(oi[0])
-    return ops.cat0(outs)
+    """Packed variable-length batch (reference: src/core.py:356-491): q [sum_q, Hq, D], k / v [sum_k, Hkv, D],
+    cu_seqlens int32 / int64 [B+1] on the device.  As in the reference, smooth-K subtracts ONE mean taken over all
+    packed tokens (`k.mean(dim=0)`, :452-454), quantisation blocks restart at every sequence, and each sequence
+    attends only to itself (causal: len_q == len_k per sequence).  The whole batch runs in one `lbfa_forward_varlen`
+    call - 5 launches whatever the number of sequences, no host read of cu_seqlens."""
+    ops, dtype = _check_inputs(q, k, v)
+    qshape = ops.shape(q)
+    if len(qshape) != 3:
+        raise ValueError("sageattn_varlen expects q of shape [total_q, num_qo_heads, head_dim]")
+    if 0 in qshape:
+        return ops.empty(qshape, dtype, q)
+    if 0 in ops.shape(k):
+        raise ValueError("k/v must hold at least one key (softmax over an empty set is undefined)")
+    assert ops.shape(cu_seqlens_q) == ops.shape(cu_seqlens_k), "cu_seqlens_q and cu_seqlens_k must have the same length"
+    q, k, v, head_dim_og = _pad_head_dim(ops, q, k, v)
+    if sm_scale is None:
+        sm_scale = 1.0 / head_dim_og ** 0.5  # :455-456
+    cu_q, cu_k = ops.as_int32(cu_seqlens_q), ops.as_int32(cu_seqlens_k)
+    lib = _lib.load()
+    total_q, Hq, D = ops.shape(q)
+    total_k, Hkv, _ = ops.shape(k)
+    B = ops.shape(cu_q)[0] - 1
+    o = ops.empty((total_q, Hq, D), dtype, q)
+    hs = lambda t: _lib.strides2((ops.strides(t)[1], ops.strides(t)[0]))  # {head, token}
+    ws_bytes = lib.lbfa_forward_varlen_workspace_bytes(B, Hq, Hkv, total_q, total_k, int(max_seqlen_q), int(max_seqlen_k), D)
+    ws = ops.empty((max(ws_bytes, 16),), ops.uint8, q)
+    with ops.device_guard(q):
+        _lib.check(lib.lbfa_forward_varlen(ops.ptr(q), ops.ptr(k), ops.ptr(v), ops.dtype_code(q), ops.ptr(o),
+                                           ops.ptr(cu_q), ops.ptr(cu_k), ops.ptr(ws), ws_bytes, B, Hq, Hkv, total_q, total_k,
+                                           int(max_seqlen_q), int(max_seqlen_k), D, hs(q), hs(k), hs(v), hs(o),
+                                           float(sm_scale), 127, 127, 1 if is_causal else 0, 1 if smooth_k else 0,
+                                           ops.stream(q)), lib)
+    return o[..., :head_dim_og]
 
 
 def manual_scaled_dot_product_attention(q, k, v, is_causal=False):

@@ -89,27 +89,47 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   if constexpr (CAUSAL) qt = p.nQ - 1 - qt;  // heaviest q-blocks of a head first
   const int b = bh / p.Hq, h = bh % p.Hq, hk = h / p.group;
 
+  // ---- extents of this problem: dense batch entry, or sequence b of a packed variable-length batch ----
+  int Sq = p.Sq, Sk = p.Sk, nK = p.nK;
+  int64_t q_off = (int64_t)b * p.qb, k_off = (int64_t)b * p.kb, v_off = (int64_t)b * p.vb, o_off = (int64_t)b * p.ob;
+  int64_t qsc_base = (int64_t)b * p.qsc_b, ksc_base = (int64_t)b * p.ksc_b;
+  if (p.cu_q != nullptr) {  // attn_qk_int8_block_varlen.py:125-141
+    const int q0 = p.cu_q[b], k0 = p.cu_k[b];
+    Sq = p.cu_q[b + 1] - q0;
+    Sk = p.cu_k[b + 1] - k0;
+    if (qt * 128 >= Sq) return;  // whole workgroup, before any barrier
+    nK = (Sk + 63) >> 6;
+    q_off = (int64_t)q0 * p.qs;
+    k_off = (int64_t)k0 * p.ks;
+    v_off = (int64_t)k0 * p.vs;
+    o_off = (int64_t)q0 * p.os;
+    if (p.cu_qscale != nullptr) {
+      qsc_base = (int64_t)p.cu_qscale[b] * p.qsc_b;
+      ksc_base = (int64_t)p.cu_kscale[b] * p.ksc_b;
+    }
+  }
+
   const int row0 = qt * 128 + wave * 32;  // first query row of this wave
   const int qrow = row0 + r;
 
   // ---- operand windows (bytes).  The descriptor is re-based per tile with scalar arithmetic, so the
   // hardware range check sees only the loop-invariant per-lane offset.
-  const char* qbase = (const char*)p.q + (int64_t)b * p.qb + (int64_t)h * p.qh;
-  const char* kbase = (const char*)p.k + (int64_t)b * p.kb + (int64_t)hk * p.kh;
-  const int64_t k_bytes = (int64_t)(p.Sk - 1) * p.ks + D;
+  const char* qbase = (const char*)p.q + q_off + (int64_t)h * p.qh;
+  const char* kbase = (const char*)p.k + k_off + (int64_t)hk * p.kh;
+  const int64_t k_bytes = (int64_t)(Sk - 1) * p.ks + D;
   const int64_t k_tile_stride = 64 * p.ks;
   const char* vbase;
   int64_t v_bytes, v_tile_stride;  // bytes between consecutive 64-key tiles
   if constexpr (FP8) {
-    vbase = (const char*)p.v + (((int64_t)b * p.Hkv + hk) * p.nK) * (int64_t)(D * 64);
-    v_bytes = (int64_t)p.nK * D * 64;
+    vbase = (const char*)p.v + (((int64_t)b * p.Hkv + hk) * nK) * (int64_t)(D * 64);
+    v_bytes = (int64_t)nK * D * 64;
     v_tile_stride = D * 64;
   } else {
-    vbase = (const char*)p.v + 2 * ((int64_t)b * p.vb + (int64_t)hk * p.vh);
-    v_bytes = 2 * ((int64_t)(p.Sk - 1) * p.vs + D);
+    vbase = (const char*)p.v + 2 * (v_off + (int64_t)hk * p.vh);
+    v_bytes = 2 * ((int64_t)(Sk - 1) * p.vs + D);
     v_tile_stride = 128 * p.vs;
   }
-  const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(qbase, (unsigned)((int64_t)(p.Sq - 1) * p.qs + D));
+  const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(qbase, (unsigned)((int64_t)(Sq - 1) * p.qs + D));
 
   // ---- Q fragments (B operand of the int8 MFMA): lane (r, hh) holds bytes [32s+16hh, +16) of its row.
   // Rows >= Sq are out of the descriptor's range and read as zeros.
@@ -117,11 +137,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
   for (int s = 0; s < KS; ++s)
     qf[s] = __builtin_bit_cast(i32x4, buf_load16(q_rs, (unsigned)qrow * (unsigned)p.qs + 16 * hh + 32 * s, 0));
-  const float qsc = p.q_scale[((int64_t)b * p.Hq + h) * p.nQ + qt];
-  const float* ksc = p.k_scale + ((int64_t)b * p.Hkv + hk) * p.nK;
+  const float qsc = p.q_scale[qsc_base + (int64_t)h * p.qsc_h + (int64_t)qt * p.qsc_blk];
+  const float* ksc = p.k_scale + ksc_base + (int64_t)hk * p.ksc_h;
+  const int ksc_blk = (int)p.ksc_blk;
 
-  int n_tiles = p.nK;
-  if constexpr (CAUSAL) n_tiles = min(p.nK, 2 * (qt + 1));
+  int n_tiles = nK;
+  if constexpr (CAUSAL) n_tiles = min(nK, 2 * (qt + 1));
 
   // ---- loop-invariant per-thread offsets: global (voffset) and LDS -----------------------------------
   unsigned k_goff[KCH], k_loff[KCH], v_goff[VCH], v_loff[VCH];
@@ -215,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   // - which may be ANY value near the row max - is kept on the same grid (rounded up by < G <= 2^-9 for
   // typical data).  |c1| <= 1.17*kMagic*sc_max < 2^21*G, so every constant is an exact multiple of G.
   float ks_max = 0.f;
-  for (int i = lane; i < p.nK; i += 64) ks_max = fmaxf(ks_max, ksc[i]);
+  for (int i = lane; i < nK; i += 64) ks_max = fmaxf(ks_max, ksc[i * ksc_blk]);
   ks_max = __builtin_amdgcn_readfirstlane(__float_as_uint(wave_max(ks_max))) ? wave_max(ks_max) : 1e-30f;
   const float sc_max = qsc * ks_max;
   const int gexp = (int)((__float_as_uint(1.25f * kMagic * sc_max) >> 23) & 0xff) - 127 + 1 - 21;  // log2(G)
@@ -232,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     const char* kbuf = smem + BUF * KBYTES;
     const char* vbuf = smem + BUF * VBYTES;
     // -- online softmax, base 2
-    const float sc = __builtin_rintf(qsc * ksc[j] * invg) * g;  // per-tile dequant scale on the g grid
+    const float sc = __builtin_rintf(qsc * ksc[j * ksc_blk] * invg) * g;  // per-tile dequant scale on the g grid
     const float c0 = -kMagic * sc;                              // exact
     float x[2][16];  // scores as floats kMagic + s (accumulator bits), then overwritten in place by P
     // -- S^T = K Q^T (int8 -> int32, biased by kMagic): two 32-key blocks
@@ -254,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
           float tv = __int_as_float(sacc[i]);
           if constexpr (MASKED) {
             const int key = j * 64 + 32 * kb2 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            bool dead = key >= p.Sk;
+            bool dead = key >= Sk;
             if constexpr (CAUSAL) dead = dead || (key > qrow);
             if (dead) tv = -INFINITY;  // fma(-inf, sc, c1) = -inf -> p = 0
           }
@@ -394,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   // (causal diagonal block = 2 tiles, ragged last tile).
   int n_main = n_tiles;
   if constexpr (CAUSAL) n_main = min(n_tiles, 2 * qt);
-  else if ((p.Sk & 63) != 0) n_main = n_tiles - 1;
+  else if ((Sk & 63) != 0) n_main = n_tiles - 1;
 
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
@@ -427,9 +448,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 
   // ---- epilogue: O = O^T / l (x v_scale), LSE ------------------------------------------------------------
   const float l_tot = l_run;  // already the sum over both lane halves
-  const float inv_l = 1.0f / l_tot;
-  if (qrow < p.Sq) {
-    unsigned short* op = reinterpret_cast<unsigned short*>(p.o) + (int64_t)b * p.ob + (int64_t)h * p.oh + (int64_t)qrow * p.os;
+  const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;  // a sequence without keys (packed batches only) yields zeros
+  if (qrow < Sq) {
+    unsigned short* op = reinterpret_cast<unsigned short*>(p.o) + o_off + (int64_t)h * p.oh + (int64_t)qrow * p.os;
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -451,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     if (p.lse != nullptr && hh == 0) {
       float ls = log2f(l_tot) + m_run;  // base-2 domain (attn_qk_int8_per_block.py:164-167)
       if constexpr (FP8) ls -= kFp8Offset;  // qk_int_sv_f8_cuda.cu:689
-      const int64_t li = ((int64_t)b * p.Hq + h) * p.Sq + qrow;
+      const int64_t li = ((int64_t)b * p.Hq + h) * p.Sq + qrow;  // dense only (the packed entry points take no lse)
       ls *= p.lse_scale;
       if (p.lse_corr != nullptr) ls += p.lse_corr[li] * p.lse_corr_scale;
       p.lse[li] = ls;

@@ -38,6 +38,12 @@ int check_hip(hipError_t e, const char* what) {
 }
 bool dims_ok(int B, int H, int S, int D) { return B > 0 && H > 0 && S > 0 && (D == 64 || D == 128); }
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+// q_scale [B,Hq,nQ], k_scale [B,Hkv,nK], no packed-batch tables
+void dense_scale_layout(lbfa::AttnParams& p) {
+  p.qsc_b = (int64_t)p.Hq * p.nQ; p.qsc_h = p.nQ; p.qsc_blk = 1;
+  p.ksc_b = (int64_t)p.Hkv * p.nK; p.ksc_h = p.nK; p.ksc_blk = 1;
+  p.cu_q = p.cu_k = p.cu_qscale = p.cu_kscale = nullptr;
+}
 }  // namespace
 
 namespace {
@@ -116,8 +122,58 @@ int lbfa_quant_per_block(const void* x, int dtype, const void* mean, int mean_gr
   p.nblk = (S + blk - 1) / blk;
   p.mean_group = mean ? mean_group : 1;
   p.rowdot_group = rowdot_vec ? rowdot_group : 1;
+  p.scale_b = (int64_t)H * p.nblk; p.scale_h = p.nblk; p.scale_blk = 1;
+  p.cu_seqlens = nullptr; p.cu_scale = nullptr; p.mean_b = 1;
   g_err[0] = 0;
   return check_hip(lbfa::launch_quant_per_block(p, dtype, D, blk, (hipStream_t)stream), "lbfa_quant_per_block launch");
+}
+
+namespace {
+// packed batch, shared by lbfa_quant_per_block_varlen (reference scale layout) and lbfa_forward_varlen (padded layout)
+int quant_varlen_core(const char* who, const void* x, int dtype, const void* mean, int mean_group, int8_t* out, float* scale,
+                      const int32_t* cu_seqlens, const int32_t* cu_scale, float sm_scale, int qmax, int blk, int B,
+                      int max_seqlen, int H, int D, const int64_t strides_x[2], const int64_t strides_out[2], void* stream) {
+  if (!x || !out || !scale || !cu_seqlens || !strides_x || !strides_out) return fail(LBFA_EINVAL, "%s: null pointer", who);
+  if (!dims_ok(B, H, max_seqlen, D)) return fail(LBFA_EINVAL, "Unsupported head_dim: %d (or empty batch %dx%dx%d)", D, B, H, max_seqlen);
+  if (dtype != LBFA_F16 && dtype != LBFA_BF16)
+    return fail(LBFA_EINVAL, "Input tensors must be in dtype of float16 or bfloat16");
+  if (qmax != 127 && qmax != 7) return fail(LBFA_EINVAL, "%s: qmax must be 127 (int8) or 7 (int4 range), got %d", who, qmax);
+  if (blk != 128 && blk != 64) return fail(LBFA_EINVAL, "%s: blk must be 128 or 64, got %d", who, blk);
+  if (mean && (mean_group <= 0 || H % mean_group != 0)) return fail(LBFA_EINVAL, "%s: bad mean_group %d for H=%d", who, mean_group, H);
+  if (!aligned16(x) || (strides_x[0] | strides_x[1]) % 8 != 0)
+    return fail(LBFA_EINVAL, "%s: x must be 16-byte aligned with strides that are multiples of 8 elements", who);
+  if ((reinterpret_cast<uintptr_t>(out) & 7u) || (strides_out[0] | strides_out[1]) % 8 != 0)
+    return fail(LBFA_EINVAL, "%s: out must be 8-byte aligned with strides that are multiples of 8", who);
+  lbfa::QuantParams p;
+  p.x = (const unsigned short*)x;
+  p.mean = (const unsigned short*)mean;
+  p.out = out;
+  p.scale = scale;
+  p.rowdot_vec = nullptr;
+  p.rowdot_out = nullptr;
+  p.xb = 0; p.xh = strides_x[0]; p.xs = strides_x[1];
+  p.ob = 0; p.oh = strides_out[0]; p.os = strides_out[1];
+  p.sm_scale = sm_scale;
+  p.qmax = (float)qmax;
+  p.B = B; p.H = H; p.S = max_seqlen;
+  p.nblk = (max_seqlen + blk - 1) / blk;  // grid extent; blocks past a sequence's end exit at once
+  p.mean_group = mean ? mean_group : 1;
+  p.rowdot_group = 1;
+  if (cu_scale) { p.scale_b = H; p.scale_h = 1; p.scale_blk = H; }              // [sum_blocks, H]
+  else { p.scale_b = (int64_t)H * p.nblk; p.scale_h = p.nblk; p.scale_blk = 1; }  // [B, H, max_blocks]
+  p.cu_seqlens = cu_seqlens; p.cu_scale = cu_scale; p.mean_b = 0;
+  g_err[0] = 0;
+  return check_hip(lbfa::launch_quant_per_block(p, dtype, D, blk, (hipStream_t)stream), who);
+}
+}  // namespace
+
+int lbfa_quant_per_block_varlen(const void* x, int dtype, const void* mean, int mean_group, int8_t* out, float* scale,
+                                const int32_t* cu_seqlens, const int32_t* cu_seqlens_scale, float sm_scale, int qmax,
+                                int blk, int B, int max_seqlen, int H, int D, const int64_t strides_x[2],
+                                const int64_t strides_out[2], void* stream) {
+  if (!cu_seqlens_scale) return fail(LBFA_EINVAL, "lbfa_quant_per_block_varlen: null pointer");
+  return quant_varlen_core("lbfa_quant_per_block_varlen", x, dtype, mean, mean_group, out, scale, cu_seqlens, cu_seqlens_scale,
+                           sm_scale, qmax, blk, B, max_seqlen, H, D, strides_x, strides_out, stream);
 }
 
 size_t lbfa_v_fp8_bytes(int B, int H, int S, int D) {
@@ -186,6 +242,7 @@ int lbfa_attn_fwd(const int8_t* q, const int8_t* k, const void* v, int v_dtype, 
   p.lse_corr = nullptr;
   p.lse_scale = 1.0f;
   p.lse_corr_scale = 0.0f;
+  dense_scale_layout(p);
   if ((int64_t)B * Hq * p.nQ > 0x7fffffffLL) return fail(LBFA_EINVAL, "lbfa_attn_fwd: grid too large");
   g_err[0] = 0;
   return check_hip(launch_attention(p, D, v_dtype, o_dtype, is_causal ? 1 : 0, (hipStream_t)stream), "lbfa_attn_fwd launch");
@@ -294,9 +351,137 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
   p.lse_corr = corr;
   p.lse_scale = 1.0f / 1.44269504f;   // natural-log LSE (src/core.py:347)
   p.lse_corr_scale = sm_scale;
+  dense_scale_layout(p);
   if ((int64_t)B * Hq * p.nQ > 0x7fffffffLL) return fail(LBFA_EINVAL, "lbfa_forward: grid too large");
   g_err[0] = 0;
   return check_hip(launch_attention(p, D, v_dtype, dtype, is_causal ? 1 : 0, (hipStream_t)stream), "lbfa_forward launch");
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// packed variable-length batches (reference: sageattn_varlen, src/core.py:356-491)
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+int attn_varlen_core(const char* who, const int8_t* q, const int8_t* k, const void* v, int v_dtype, void* o, int o_dtype,
+                     const float* q_scale, const float* k_scale, const int32_t* cu_q, const int32_t* cu_k,
+                     const int32_t* cu_qscale, const int32_t* cu_kscale, int B, int Hq, int Hkv, int max_q, int max_k, int D,
+                     const int64_t sq[2], const int64_t sk[2], const int64_t sv[2], const int64_t so[2], int is_causal,
+                     void* stream) {
+  if (!q || !k || !v || !o || !q_scale || !k_scale || !cu_q || !cu_k || !sq || !sk || !sv || !so)
+    return fail(LBFA_EINVAL, "%s: null pointer", who);
+  if ((cu_qscale == nullptr) != (cu_kscale == nullptr)) return fail(LBFA_EINVAL, "%s: give both scale offset tables or neither", who);
+  if (B <= 0 || Hq <= 0 || Hkv <= 0 || max_q <= 0 || max_k <= 0) return fail(LBFA_EINVAL, "%s: empty batch", who);
+  if (D != 64 && D != 128) return fail(LBFA_EINVAL, "Unsupported head_dim: %d", D);
+  if (Hq % Hkv != 0) return fail(LBFA_EINVAL, "num_qo_heads (%d) must be divisible by num_kv_heads (%d)", Hq, Hkv);
+  if (v_dtype != LBFA_F16 && v_dtype != LBFA_BF16) return fail(LBFA_EINVAL, "%s: v must be float16 or bfloat16", who);
+  if (o_dtype != LBFA_F16 && o_dtype != LBFA_BF16) return fail(LBFA_EINVAL, "%s: bad o_dtype %d", who, o_dtype);
+  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (reinterpret_cast<uintptr_t>(o) & 7u))
+    return fail(LBFA_EINVAL, "%s: q/k/v must be 16-byte aligned and o 8-byte aligned", who);
+  if ((sq[0] | sq[1] | sk[0] | sk[1]) % 16 != 0) return fail(LBFA_EINVAL, "%s: q/k strides must be multiples of 16 elements", who);
+  if ((sv[0] | sv[1]) % 8 != 0) return fail(LBFA_EINVAL, "%s: v strides must be multiples of 8 elements", who);
+  if ((so[0] | so[1]) % 4 != 0) return fail(LBFA_EINVAL, "%s: o strides must be multiples of 4 elements", who);
+  {
+    const int64_t lim = 0x7fffffffLL;
+    if (((int64_t)max_q + LBFA_BLKQ) * sq[1] + D > lim || ((int64_t)max_k + 2 * LBFA_BLKK) * sk[1] + D > lim ||
+        2 * (((int64_t)max_k + 2 * LBFA_BLKK) * sv[1] + D) > lim)
+      return fail(LBFA_EINVAL, "%s: per-sequence operand window exceeds 2 GiB (token stride x max_seqlen too large)", who);
+  }
+  lbfa::AttnParams p;
+  p.q = q; p.k = k; p.v = v; p.o = o; p.lse = nullptr;
+  p.q_scale = q_scale; p.k_scale = k_scale; p.v_scale = nullptr;
+  p.qb = 0; p.qh = sq[0]; p.qs = sq[1];
+  p.kb = 0; p.kh = sk[0]; p.ks = sk[1];
+  p.vb = 0; p.vh = sv[0]; p.vs = sv[1];
+  p.ob = 0; p.oh = so[0]; p.os = so[1];
+  p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Sq = max_q; p.Sk = max_k;
+  p.nQ = (max_q + LBFA_BLKQ - 1) / LBFA_BLKQ;
+  p.nK = (max_k + LBFA_BLKK - 1) / LBFA_BLKK;
+  p.group = Hq / Hkv;
+  p.lse_corr = nullptr; p.lse_scale = 1.0f; p.lse_corr_scale = 0.0f;
+  dense_scale_layout(p);  // padded [B,H,max_blocks] unless the reference's packed tables are given
+  if (cu_qscale) {
+    p.qsc_b = Hq; p.qsc_h = 1; p.qsc_blk = Hq;      // [sum_q_blocks, Hq]  (attn_qk_int8_block_varlen.py:134-138)
+    p.ksc_b = Hkv; p.ksc_h = 1; p.ksc_blk = Hkv;    // [sum_k_blocks, Hkv]
+  }
+  p.cu_q = cu_q; p.cu_k = cu_k; p.cu_qscale = cu_qscale; p.cu_kscale = cu_kscale;
+  if ((int64_t)B * Hq * p.nQ > 0x7fffffffLL) return fail(LBFA_EINVAL, "%s: grid too large", who);
+  g_err[0] = 0;
+  return check_hip(launch_attention(p, D, v_dtype, o_dtype, is_causal ? 1 : 0, (hipStream_t)stream), who);
+}
+
+struct VarlenLayout {
+  size_t km, part, q8, k8, qs, ks, total;
+};
+VarlenLayout varlen_layout(int B, int Hq, int Hkv, int total_q, int total_k, int max_q, int max_k, int D) {
+  VarlenLayout L;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t at = o; o += align256(n); return at; };
+  L.km = take((size_t)Hkv * D * 2);
+  L.part = take(lbfa_mean_seq_workspace_bytes(1, Hkv, total_k, D));
+  L.q8 = take((size_t)total_q * Hq * D);
+  L.k8 = take((size_t)total_k * Hkv * D);
+  L.qs = take((size_t)B * Hq * ((max_q + LBFA_BLKQ - 1) / LBFA_BLKQ) * 4);
+  L.ks = take((size_t)B * Hkv * ((max_k + LBFA_BLKK - 1) / LBFA_BLKK) * 4);
+  L.total = o;
+  return L;
+}
+}  // namespace
+
+int lbfa_attn_fwd_varlen(const int8_t* q, const int8_t* k, const void* v, int v_dtype, void* o, int o_dtype,
+                         const float* q_scale, const float* k_scale, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                         const int32_t* cu_seqlens_q_scale, const int32_t* cu_seqlens_k_scale,
+                         int B, int Hq, int Hkv, int max_seqlen_q, int max_seqlen_k, int D,
+                         const int64_t strides_q[2], const int64_t strides_k[2], const int64_t strides_v[2],
+                         const int64_t strides_o[2], int is_causal, void* stream) {
+  if (!cu_seqlens_q_scale || !cu_seqlens_k_scale) return fail(LBFA_EINVAL, "lbfa_attn_fwd_varlen: null pointer");
+  return attn_varlen_core("lbfa_attn_fwd_varlen", q, k, v, v_dtype, o, o_dtype, q_scale, k_scale, cu_seqlens_q, cu_seqlens_k,
+                          cu_seqlens_q_scale, cu_seqlens_k_scale, B, Hq, Hkv, max_seqlen_q, max_seqlen_k, D, strides_q, strides_k,
+                          strides_v, strides_o, is_causal, stream);
+}
+
+size_t lbfa_forward_varlen_workspace_bytes(int B, int Hq, int Hkv, int total_q, int total_k, int max_seqlen_q,
+                                           int max_seqlen_k, int D) {
+  if (B <= 0 || Hq <= 0 || Hkv <= 0 || total_q <= 0 || total_k <= 0 || max_seqlen_q <= 0 || max_seqlen_k <= 0 || D <= 0) return 0;
+  return varlen_layout(B, Hq, Hkv, total_q, total_k, max_seqlen_q, max_seqlen_k, D).total;
+}
+
+int lbfa_forward_varlen(const void* q, const void* k, const void* v, int dtype, void* o,
+                        const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, void* workspace, size_t workspace_bytes,
+                        int B, int Hq, int Hkv, int total_q, int total_k, int max_seqlen_q, int max_seqlen_k, int D,
+                        const int64_t strides_q[2], const int64_t strides_k[2], const int64_t strides_v[2],
+                        const int64_t strides_o[2], float sm_scale, int q_qmax, int k_qmax, int is_causal, int smooth_k,
+                        void* stream) {
+  if (!q || !k || !v || !o || !workspace || !cu_seqlens_q || !cu_seqlens_k || !strides_q || !strides_k || !strides_v || !strides_o)
+    return fail(LBFA_EINVAL, "lbfa_forward_varlen: null pointer");
+  if (B <= 0 || Hq <= 0 || Hkv <= 0 || total_q <= 0 || total_k <= 0 || max_seqlen_q <= 0 || max_seqlen_k <= 0)
+    return fail(LBFA_EINVAL, "lbfa_forward_varlen: empty batch");
+  if (D != 64 && D != 128) return fail(LBFA_EINVAL, "Unsupported head_dim: %d", D);
+  if (Hq % Hkv != 0) return fail(LBFA_EINVAL, "num_qo_heads (%d) must be divisible by num_kv_heads (%d)", Hq, Hkv);
+  const VarlenLayout L = varlen_layout(B, Hq, Hkv, total_q, total_k, max_seqlen_q, max_seqlen_k, D);
+  if (workspace_bytes < L.total) return fail(LBFA_EINVAL, "lbfa_forward_varlen: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+  if (!aligned16(workspace)) return fail(LBFA_EINVAL, "lbfa_forward_varlen: workspace must be 16-byte aligned");
+  char* ws = (char*)workspace;
+  void* km = smooth_k ? (void*)(ws + L.km) : nullptr;
+  int8_t* q8 = (int8_t*)(ws + L.q8);
+  int8_t* k8 = (int8_t*)(ws + L.k8);
+  float* qs = (float*)(ws + L.qs);
+  float* ks = (float*)(ws + L.ks);
+  const int64_t sq8[2] = {D, (int64_t)Hq * D};  // int8 codes: contiguous [tokens, H, D]
+  const int64_t sk8[2] = {D, (int64_t)Hkv * D};
+  int st;
+  if (smooth_k) {  // km = k.mean(dim=0): over ALL tokens of the packed batch (src/core.py:453)
+    const int64_t sk3[3] = {0, strides_k[0], strides_k[1]};
+    st = lbfa_mean_seq(k, dtype, km, ws + L.part, lbfa_mean_seq_workspace_bytes(1, Hkv, total_k, D), 1, Hkv, total_k, D, sk3, stream);
+    if (st) return st;
+  }
+  st = quant_varlen_core("lbfa_forward_varlen (Q)", q, dtype, nullptr, 1, q8, qs, cu_seqlens_q, nullptr, sm_scale * 1.44269504f,
+                         q_qmax, LBFA_BLKQ, B, max_seqlen_q, Hq, D, strides_q, sq8, stream);
+  if (st) return st;
+  st = quant_varlen_core("lbfa_forward_varlen (K)", k, dtype, km, 1, k8, ks, cu_seqlens_k, nullptr, 1.0f, k_qmax, LBFA_BLKK, B,
+                         max_seqlen_k, Hkv, D, strides_k, sk8, stream);
+  if (st) return st;
+  return attn_varlen_core("lbfa_forward_varlen", q8, k8, v, dtype, o, dtype, qs, ks, cu_seqlens_q, cu_seqlens_k, nullptr, nullptr,
+                          B, Hq, Hkv, max_seqlen_q, max_seqlen_k, D, sq8, sk8, strides_v, strides_o, is_causal, stream);
 }
 
 }  // extern "C"

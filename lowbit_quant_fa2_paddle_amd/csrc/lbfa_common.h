@@ -77,6 +77,15 @@ struct QuantParams {
   int64_t xb, xh, xs, ob, oh, os;
   float sm_scale, qmax;
   int B, H, S, nblk, mean_group, rowdot_group;
+  // scale index = base(b) + h * scale_h + blk * scale_blk, base(b) = (cu_scale ? cu_scale[b] : b) * scale_b.
+  // Dense [B,H,nblk]: (H*nblk, nblk, 1).  The reference's packed layout [sum_blocks, H]
+  // (src/triton/quant_per_block_varlen.py:60,101-106): (H, 1, H) with cu_scale.
+  int64_t scale_b, scale_h, scale_blk;
+  // Packed variable-length batch (src/core.py:356-491): sequence b owns tokens [cu_seqlens[b], cu_seqlens[b+1]) of
+  // x / out (batch strides unused), blocks restart at each sequence.  null = dense.
+  const int* cu_seqlens;
+  const int* cu_scale;
+  int mean_b;  // 1: mean / rowdot_vec are per batch entry; 0: one vector set shared by all (varlen k.mean(dim=0), :453)
 };
 
 struct AttnParams {
@@ -94,6 +103,13 @@ struct AttnParams {
   // lbfa_attn_fwd uses (1, null): the raw base-2 value the reference kernel stores.
   const float* lse_corr;
   float lse_scale, lse_corr_scale;
+  // scale addressing as in QuantParams; packed variable-length batch when cu_q != null (then cu_k too):
+  // (src/triton/attn_qk_int8_block_varlen.py:125-160), Sq / Sk / nQ / nK hold the maxima over the batch.
+  int64_t qsc_b, qsc_h, qsc_blk, ksc_b, ksc_h, ksc_blk;
+  const int* cu_q;
+  const int* cu_k;
+  const int* cu_qscale;
+  const int* cu_kscale;
 };
 
 }  // namespace lbfa

@@ -91,14 +91,25 @@ __global__ __launch_bounds__(256) void quant_per_block_kernel(QuantParams p) {
   __shared__ float wmax[4];
   const int blk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int t = threadIdx.x, c = t % CPR, rl = t / CPR;
-  const unsigned short* xbase = p.x + (int64_t)b * p.xb + (int64_t)h * p.xh + c * 8;
-  int8_t* obase = p.out + (int64_t)b * p.ob + (int64_t)h * p.oh + c * 8;
+  int S = p.S;
+  int64_t xoff = (int64_t)b * p.xb, ooff = (int64_t)b * p.ob, sbase = (int64_t)b * p.scale_b;
+  if (p.cu_seqlens != nullptr) {  // packed batch: sequence b (quant_per_block_varlen.py:41-48)
+    const int s0 = p.cu_seqlens[b];
+    S = p.cu_seqlens[b + 1] - s0;
+    if (blk * BLK >= S) return;
+    xoff = (int64_t)s0 * p.xs;
+    ooff = (int64_t)s0 * p.os;
+    if (p.cu_scale != nullptr) sbase = (int64_t)p.cu_scale[b] * p.scale_b;
+  }
+  const unsigned short* xbase = p.x + xoff + (int64_t)h * p.xh + c * 8;
+  int8_t* obase = p.out + ooff + (int64_t)h * p.oh + c * 8;
+  const int vb = b * p.mean_b;  // which mean / rowdot vector set
 
   float mean[8], vec[8];
   if constexpr (HAS_MEAN)
-    unpack8<DT>(*reinterpret_cast<const uint4*>(p.mean + ((int64_t)b * (p.H / p.mean_group) + h / p.mean_group) * D + c * 8), mean);
+    unpack8<DT>(*reinterpret_cast<const uint4*>(p.mean + ((int64_t)vb * (p.H / p.mean_group) + h / p.mean_group) * D + c * 8), mean);
   if constexpr (HAS_DOT)
-    unpack8<DT>(*reinterpret_cast<const uint4*>(p.rowdot_vec + ((int64_t)b * (p.H / p.rowdot_group) + h / p.rowdot_group) * D + c * 8), vec);
+    unpack8<DT>(*reinterpret_cast<const uint4*>(p.rowdot_vec + ((int64_t)vb * (p.H / p.rowdot_group) + h / p.rowdot_group) * D + c * 8), vec);
 
   // all loads of the block first (NP independent 16-byte loads in flight per lane), then the arithmetic
   uint4 raw[NP];
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(256) void quant_per_block_kernel(QuantParams p) {
   for (int ps = 0; ps < NP; ++ps) {
     const int row = blk * BLK + ps * RPP + rl;
     raw[ps] = make_uint4(0, 0, 0, 0);  // masked rows load as 0 (quant_per_block.py:170)
-    if (row < p.S) raw[ps] = *reinterpret_cast<const uint4*>(xbase + (int64_t)row * p.xs);
+    if (row < S) raw[ps] = *reinterpret_cast<const uint4*>(xbase + (int64_t)row * p.xs);
   }
   float xs[NP][8];
   float amax = 0.f;
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(256) void quant_per_block_kernel(QuantParams p) {
       for (int i = 0; i < 8; ++i) dot += v[i] * vec[i];
 #pragma unroll
       for (int o = CPR / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
-      if (c == 0 && row < p.S) p.rowdot_out[((int64_t)b * p.H + h) * p.S + row] = load_cvt<DT>(store_cvt<DT>(dot));
+      if (c == 0 && row < S) p.rowdot_out[((int64_t)b * p.H + h) * S + row] = load_cvt<DT>(store_cvt<DT>(dot));
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -129,7 +140,7 @@ __global__ __launch_bounds__(256) void quant_per_block_kernel(QuantParams p) {
       // `k - km` is an elementwise op in the storage dtype (quant_per_block.py:186-187): the fp32 difference
       // is rounded to that dtype, as the CPU oracle (and torch/paddle CPU) does.  Rows past the end stay 0:
       // the reference subtracts on the real tensor, then loads masked rows as 0.
-      if constexpr (HAS_MEAN) x = (row < p.S) ? load_cvt<DT>(store_cvt<DT>(x - mean[i])) : 0.f;
+      if constexpr (HAS_MEAN) x = (row < S) ? load_cvt<DT>(store_cvt<DT>(x - mean[i])) : 0.f;
       x *= p.sm_scale;
       xs[ps][i] = x;
       amax = fmaxf(amax, fabsf(x));
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(256) void quant_per_block_kernel(QuantParams p) {
   __syncthreads();
   amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
   const float scale = fmaxf(amax, 1e-7f) / p.qmax;
-  if (t == 0) p.scale[((int64_t)b * p.H + h) * p.nblk + blk] = scale;
+  if (t == 0) p.scale[sbase + (int64_t)h * p.scale_h + (int64_t)blk * p.scale_blk] = scale;
 
   // y = xs / scale must be the correctly rounded fp32 quotient (the codes are bit-exact against the oracle).
   // A full IEEE division per element costs ~12 VALU ops; the divisor is the same for the whole block, so use
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(256) void quant_per_block_kernel(QuantParams p) {
       const unsigned p67 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(q[6], q[7]));
       const unsigned w0 = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
       const unsigned w1 = __builtin_amdgcn_perm(p67, p45, 0x06040200u);
-      if (row < p.S) *reinterpret_cast<uint2*>(obase + (int64_t)row * p.os) = make_uint2(w0, w1);
+      if (row < S) *reinterpret_cast<uint2*>(obase + (int64_t)row * p.os) = make_uint2(w0, w1);
     }
   };
   if (exact_rcp_ok) encode(std::true_type{});

@@ -396,6 +396,74 @@ def lowbit_fa_forward(q, k, v, *, dtype: str = "fp16", tensor_layout: str = "HND
 
 
 # --------------------------------------------------------------------------------------
+# Packed variable-length batches  (src/core.py:356-491)
+# --------------------------------------------------------------------------------------
+def lowbit_fa_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, *, dtype: str = "fp16", is_causal: bool = False,
+                     sm_scale=None, smooth_k: bool = True, q_qmax: float = 127.0, k_qmax: float = 127.0,
+                     tail: str = "reference", amax_floor: float = 0.0, return_intermediates: bool = False):
+    """`sageattn_varlen` (src/core.py:356-491).  q [total_q, Hq, D], k / v [total_k, Hkv, D] fp32-valued arrays
+    already rounded to `dtype`; cu_seqlens_* integer sequences of B + 1 entries.
+
+    Steps: pad D (:431-440); bf16 -> v.half() (:449-450); km = k.mean(dim=0) over ALL packed tokens, k - km in
+    the storage dtype (:451-454); sm_scale = D_og^-0.5 (:455-456); per sequence, with blocks restarting at the
+    sequence start (src/triton/quant_per_block_varlen.py:41-72): Q * sm_scale*1.44269504 -> int8 per 128 rows,
+    K -> int8 per 64 rows; per sequence the same tile loop as the dense kernel
+    (src/triton/attn_qk_int8_block_varlen.py:24-92, causal: attn_qk_int8_per_block_causal_varlen.py:24-84);
+    slice (:490).  Returns o [total_q, Hq, D_og] (and, on request, the packed codes and the scales in the
+    reference layout [sum_blocks, H])."""
+    head_dim_og = q.shape[-1]
+    q, k, v = _pad_head_dim(q), _pad_head_dim(k), _pad_head_dim(v)
+    cq = [int(x) for x in cu_seqlens_q]
+    ck = [int(x) for x in cu_seqlens_k]
+    assert len(cq) == len(ck)
+    v16 = v.astype(np.float16).astype(np.float32)
+    km = None
+    if smooth_k:
+        km = to_storage(np.mean(k.astype(np.float64), axis=0, keepdims=True).astype(np.float32), dtype)  # [1,Hkv,D]
+        k = to_storage(k.astype(np.float32) - km.astype(np.float32), dtype)
+    if sm_scale is None:
+        sm_scale = 1.0 / head_dim_og ** 0.5
+    o = np.zeros(q.shape, np.float32)
+    q_i8 = np.zeros(q.shape, np.int8)
+    k_i8 = np.zeros(k.shape, np.int8)
+    q_scales, k_scales = [], []
+    for b in range(len(cq) - 1):
+        qb = np.transpose(q[cq[b]:cq[b + 1]], (1, 0, 2))[None]   # [1,Hq,len,D]
+        kb = np.transpose(k[ck[b]:ck[b + 1]], (1, 0, 2))[None]
+        vb = np.transpose(v16[ck[b]:ck[b + 1]], (1, 0, 2))[None]
+        if qb.shape[2] == 0:
+            continue
+        qi, qs = quant_per_block(qb, np.float32(float(sm_scale) * LOG2E), q_qmax, 128, amax_floor)
+        q_i8[cq[b]:cq[b + 1]] = np.transpose(qi[0], (1, 0, 2))
+        q_scales.append(np.transpose(qs[0], (1, 0)))             # [blocks, Hq]
+        if kb.shape[2] == 0:
+            continue  # l = 1, acc = 0 -> zeros (attn_qk_int8_block_varlen.py:171-173)
+        ki, ks = quant_per_block(kb, 1.0, k_qmax, 64, amax_floor)
+        k_i8[ck[b]:ck[b + 1]] = np.transpose(ki[0], (1, 0, 2))
+        k_scales.append(np.transpose(ks[0], (1, 0)))
+        ob, _ = attn_fwd_int8_fp16(qi, ki, vb, qs, ks, causal=is_causal, out_dtype=dtype, return_lse=False, tail=tail)
+        o[cq[b]:cq[b + 1]] = np.transpose(ob[0], (1, 0, 2))
+    o = o[..., :head_dim_og]
+    if return_intermediates:
+        return o, dict(q_i8=q_i8, k_i8=k_i8, km=km,
+                       q_scale=np.concatenate(q_scales, axis=0) if q_scales else np.zeros((0, q.shape[1]), np.float32),
+                       k_scale=np.concatenate(k_scales, axis=0) if k_scales else np.zeros((0, k.shape[1]), np.float32))
+    return o
+
+
+def make_varlen_inputs(lens_q, lens_k, Hq, Hkv, D, *, seed=0, dtype="fp16", k_bias=0.0):
+    """Seeded packed inputs: q [sum(lens_q), Hq, D], k / v [sum(lens_k), Hkv, D] ~ N(0,1) rounded to `dtype`."""
+    rng = np.random.default_rng(seed)
+    tq, tk = int(sum(lens_q)), int(sum(lens_k))
+    q = to_storage(rng.standard_normal((tq, Hq, D), dtype=np.float32), dtype)
+    k = to_storage(rng.standard_normal((tk, Hkv, D), dtype=np.float32) + np.float32(k_bias), dtype)
+    v = to_storage(rng.standard_normal((tk, Hkv, D), dtype=np.float32), dtype)
+    cu_q = np.concatenate([[0], np.cumsum(lens_q)]).astype(np.int32)
+    cu_k = np.concatenate([[0], np.cumsum(lens_k)]).astype(np.int32)
+    return q, k, v, cu_q, cu_k
+
+
+# --------------------------------------------------------------------------------------
 # CPU baseline: the repo's naive SDPA  (src/core.py:46-69)
 # --------------------------------------------------------------------------------------
 def sdpa_naive(q, k, v, is_causal: bool = False, sm_scale=None, return_lse: bool = False):

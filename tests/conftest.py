@@ -18,7 +18,13 @@ def pytest_configure(config):
 
 
 def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+    """dense-batch fixtures"""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith("varlen_"))
+
+
+def varlen_golden_names():
+    """packed variable-length fixtures (reference varlen kernels)"""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("varlen_"))
 
 
 def load_golden(name):

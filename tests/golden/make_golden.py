@@ -15,6 +15,9 @@ the reference kernels are launched directly:
     quant_per_block_int4_unpack_kernel   src/triton/quant_per_block.py:22-71
     _attn_fwd (non-causal)               src/triton/attn_qk_int8_per_block.py:69-167
     _attn_fwd (causal)                   src/triton/attn_qk_int8_per_block_causal.py:82-214
+    quant_per_block_int8_kernel (varlen) src/triton/quant_per_block_varlen.py:22-72
+    _attn_fwd (varlen)                   src/triton/attn_qk_int8_block_varlen.py:94-197
+    _attn_fwd (varlen, causal)           src/triton/attn_qk_int8_per_block_causal_varlen.py:83-203
 
 Outputs: tests/golden/<case>.npz holding the case parameters, a checksum of the seeded inputs
 (inputs are regenerated from the seed by oracle.make_inputs), km, int8 codes, scales, O (fp16/bf16
@@ -54,6 +57,10 @@ def _load(name, rel):
 ref_quant = _load("ref_quant_per_block", "src/triton/quant_per_block.py")
 ref_attn = _load("ref_attn_noncausal", "src/triton/attn_qk_int8_per_block.py")
 ref_attn_c = _load("ref_attn_causal", "src/triton/attn_qk_int8_per_block_causal.py")
+
+ref_quant_vl = _load("ref_quant_per_block_varlen", "src/triton/quant_per_block_varlen.py")
+ref_attn_vl = _load("ref_attn_varlen", "src/triton/attn_qk_int8_block_varlen.py")
+ref_attn_vl_c = _load("ref_attn_varlen_causal", "src/triton/attn_qk_int8_per_block_causal_varlen.py")
 
 TDT = {"fp16": torch.float16, "bf16": torch.bfloat16}
 
@@ -141,6 +148,66 @@ def run_case(name, B, H, S, D, layout="HND", causal=False, dtype="fp16", Hkv=Non
     print(f"{name}: o {tuple(o.shape)} |o|max {o.float().abs().max():.4f}")
 
 
+def ref_quantize_varlen(x, cu, max_len, sm_scale, blk):
+    """One launch as src/triton/quant_per_block_varlen.py:86-124 (scale layout [sum_blocks, H], :92-106)."""
+    h, C = x.shape[1], x.shape[2]
+    b = cu.shape[0] - 1
+    lens = cu[1:] - cu[:-1]
+    cu_scale = torch.nn.functional.pad(torch.cumsum((lens + blk - 1) // blk, dim=0), (1, 0), value=0).to(torch.int32)
+    out = torch.empty(x.shape, dtype=torch.int8)
+    scale = torch.empty((int(cu_scale[-1]), h), dtype=torch.float32)
+    grid = ((max_len + blk - 1) // blk, h, b)
+    ref_quant_vl.quant_per_block_int8_kernel[grid](x, out, scale, cu, cu_scale, x.stride(1), x.stride(0), out.stride(1),
+                                                   out.stride(0), sm_scale=sm_scale, H=h, C=C, BLK=blk)
+    return out, scale, cu_scale
+
+
+def run_varlen_case(name, lens_q, lens_k, Hq, Hkv, D, causal=False, dtype="fp16", k_bias=0.0, seed=0, smooth_k=True):
+    q, k, v, cu_q, cu_k = orc.make_varlen_inputs(lens_q, lens_k, Hq, Hkv, D, seed=seed, dtype=dtype, k_bias=k_bias)
+    digest = hashlib.sha256(b"".join(np.ascontiguousarray(a).tobytes() for a in (q, k, v))).hexdigest()
+    tq, tk, tv = (torch.from_numpy(a).to(TDT[dtype]) for a in (q, k, v))
+    tcq, tck = torch.from_numpy(cu_q), torch.from_numpy(cu_k)
+    head_dim_og = D
+    tq, tk, tv = pad_d(tq), pad_d(tk), pad_d(tv)  # src/core.py:431-440
+    if dtype == "bf16":
+        tv = tv.to(torch.float16)  # :449-450
+    if smooth_k:
+        km = tk.mean(dim=0, keepdim=True)  # :452-454
+        tk = tk - km
+    else:
+        km = None
+    sm_scale = 1.0 / head_dim_og ** 0.5
+    max_q, max_k = int(max(lens_q)), int(max(lens_k))
+    q8, q_scale, cu_qs = ref_quantize_varlen(tq, tcq, max_q, sm_scale * 1.44269504, 128)
+    k8, k_scale, cu_ks = ref_quantize_varlen(tk, tck, max_k, 1.0, 64)
+    o = torch.zeros(tq.shape, dtype=TDT[dtype])
+    b = len(lens_q)
+    grid = ((max_q + 127) // 128, Hq, b)
+    mod = ref_attn_vl_c if causal else ref_attn_vl
+    # launch as attn_qk_int8_block_varlen.py:216-247 / attn_qk_int8_per_block_causal_varlen.py:228-259
+    mod._attn_fwd[grid](q8, k8, tv, tcq, tck, q_scale, k_scale, cu_qs, cu_ks, o, tq.stride(1), tq.stride(0), k8.stride(1),
+                        k8.stride(0), tv.stride(1), tv.stride(0), o.stride(1), o.stride(0), Hq, Hq // Hkv,
+                        BLOCK_M=128, BLOCK_N=64, HEAD_DIM=tq.shape[-1], STAGE=3 if causal else 1)
+    o = o[..., :head_dim_og]
+    obits = o.contiguous().view(torch.int16).numpy().view(np.uint16)
+    params = dict(name=name, lens_q=list(map(int, lens_q)), lens_k=list(map(int, lens_k)), Hq=Hq, Hkv=Hkv, D=D, causal=causal,
+                  dtype=dtype, k_bias=k_bias, seed=seed, smooth_k=smooth_k)
+    kmn = (km.float().numpy() if km is not None else np.zeros(0, np.float32))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), params=json.dumps(params), input_sha256=digest, km=kmn,
+                        q_i8=q8.numpy(), k_i8=k8.numpy(), q_scale=q_scale.numpy(), k_scale=k_scale.numpy(),
+                        cu_q_scale=cu_qs.numpy(), cu_k_scale=cu_ks.numpy(), o_bits=obits)
+    print(f"{name}: o {tuple(o.shape)} |o|max {o.float().abs().max():.4f}")
+
+
+# K lengths are multiples of 64: for ragged key tails the reference kernel lets the padded keys into the softmax
+# as zeros (SURVEY 2.4-7), which the HIP path deliberately does not reproduce.  Query lengths are ragged.
+VARLEN_CASES = [
+    dict(name="varlen_h4_kv2_d64", lens_q=[128, 200, 64], lens_k=[192, 256, 64], Hq=4, Hkv=2, D=64, k_bias=0.3, seed=11),
+    dict(name="varlen_h4_kv2_d64_causal", lens_q=[192, 256, 64], lens_k=[192, 256, 64], Hq=4, Hkv=2, D=64, k_bias=0.3,
+         seed=11, causal=True),
+    dict(name="varlen_bf16_d128", lens_q=[70, 130], lens_k=[128, 64], Hq=2, Hkv=2, D=128, dtype="bf16", seed=12),
+]
+
 CASES = [
     dict(name="c1_hnd_s256_d64", B=1, H=2, S=256, D=64),  # BASELINE config 1
     dict(name="c1_hnd_s256_d64_causal", B=1, H=2, S=256, D=64, causal=True),
@@ -158,5 +225,10 @@ CASES = [
 ]
 
 if __name__ == "__main__":
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
     for c in CASES:
-        run_case(**c)
+        if only in c["name"]:
+            run_case(**c)
+    for c in VARLEN_CASES:
+        if only in c["name"]:
+            run_varlen_case(**c)

@@ -148,6 +148,12 @@ void run(const char* name, int threads, int split, int ops_a, int ops_b) {
 
 int main() {
 #define SWEEP(M, name, ops) run<M, M, 0>(name, 256, 0, ops, ops); run<M, M, 0>(name, 512, 0, ops, ops); run<M, M, 0>(name, 768, 0, ops, ops); run<M, M, 0>(name, 1024, 0, ops, ops);
+  SWEEP(M_FMA, "v_fma_f32 x32", 32)
+  SWEEP(M_ADD, "v_add_f32 x32", 32)
+  SWEEP(M_PKFMA, "v_pk_fma_f32 x16 (32 elems)", 16)
+  SWEEP(M_PKADD, "v_pk_add_f32 x16 (32 elems)", 16)
+  SWEEP(M_PKMUL, "v_pk_mul_f32 x16 (32 elems)", 16)
+  SWEEP(M_EXP, "v_exp_f32 x32", 32)
   SWEEP(M_EXPH, "v_exp_f16 x32", 32)
   SWEEP(M_PKRTZ, "v_cvt_pkrtz_f16_f32 x32", 32)
   SWEEP(M_MAXI3, "v_max3_i32 x32", 32)

@@ -147,6 +147,10 @@ int lbfa_profile_next_attn(void* start_event, void* stop_event);
  *   workspace: >= lbfa_forward_workspace_bytes(...) bytes, 16-byte aligned, caller-owned scratch (int8 codes,
  *             scales, km, partial sums, fp8 V); contents are undefined afterwards.
  *   sm_scale: softmax scale (1/sqrt(original head_dim) by default on the host side); q_qmax/k_qmax in {127, 7}.
+ *   D       : head dim of q, k, v, o - 64, 128, or ANY multiple of 8 up to 128: the kernels then work on 64 / 128
+ *             channels and treat the missing ones as the zero padding of src/core.py:277-287 (never read, never
+ *             written), so the host makes no padded copies; results are bit-identical to padding on the host.
+ *             (lbfa_forward_varlen likewise; the modular entry points take D in {64, 128} only.)
  */
 size_t lbfa_forward_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int pv_fp8, int smooth_k, int return_lse);
 int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o, float* lse, void* workspace,

@@ -47,6 +47,11 @@ def _pad_head_dim(ops, q, k, v):
         raise ValueError(f"Unsupported head_dim: {head_dim_og}")
     else:
         pad = 0
+    # The one-call entry points take any head dim that is a multiple of 8 and treat channels up to 64 / 128 as the
+    # zero padding of src/core.py:277-287 inside the kernels (never read, never written): no padded copies of q, k, v.
+    # Other head dims (16-byte vector loads need rows of 8 elements) are padded here, as the reference does.
+    if pad and head_dim_og % 8 == 0:
+        pad = 0
     if pad:
         q, k, v = ops.pad_last(q, pad), ops.pad_last(k, pad), ops.pad_last(v, pad)
     assert ops.strides(q)[-1] == 1 and ops.strides(k)[-1] == 1 and ops.strides(v)[-1] == 1, \

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     v_tile_stride = D * 64;
   } else {
     vbase = (const char*)p.v + 2 * (v_off + (int64_t)hk * p.vh);
-    v_bytes = 2 * ((int64_t)(Sk - 1) * p.vs + D);
+    v_bytes = 2 * ((int64_t)(Sk - 1) * p.vs + p.d_valid);
     v_tile_stride = 128 * p.vs;
   }
   const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(qbase, (unsigned)((int64_t)(Sq - 1) * p.qs + D));
@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       v_loff[i] = 2 * KBYTES + (t + 256 * i) * 16;
     } else {
       const int c = t + 256 * i, row = c / (D / 8), ch = c % (D / 8);
-      v_goff[i] = 2 * ((unsigned)row * (unsigned)p.vs) + ch * 16;
+      // padded channels: an offset beyond any window -> the range check returns zeros
+      v_goff[i] = ch * 8 < p.d_valid ? 2 * ((unsigned)row * (unsigned)p.vs) + ch * 16 : 0x80000000u;  // windows are < 2 GiB (checked by the C ABI)
       v_loff[i] = 2 * KBYTES + row * (2 * D) + (((ch >> 2) ^ vx<D>(row)) << 6) + ((ch & 3) << 4);
     }
   }
@@ -456,6 +457,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int d0 = 32 * db + 8 * g4 + 4 * hh;
+        if (d0 >= p.d_valid) continue;  // d_valid is a multiple of 8
         float o4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) o4[e] = acc_o[db][4 * g4 + e] * inv_l;

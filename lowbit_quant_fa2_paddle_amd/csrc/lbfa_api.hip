@@ -10,11 +10,11 @@ namespace lbfa {
 // defined in quant_kernels.hip / attn_fwd.hip
 int mean_rows_per_split(int S);
 size_t v_fp8_payload_bytes(int B, int H, int S, int D);
-hipError_t launch_mean_seq(const void* x, int dtype, void* out, void* ws, int B, int H, int S, int D,
+hipError_t launch_mean_seq(const void* x, int dtype, void* out, void* ws, int B, int H, int S, int D, int d_valid,
                            const int64_t* st, hipStream_t stream);
 hipError_t launch_quant_per_block(const QuantParams& p, int dtype, int D, int blk, hipStream_t stream);
 hipError_t launch_quant_v_fp8(const void* v, int dtype, uint8_t* out, float* v_scale, int B, int H, int S, int D,
-                              const int64_t* st, hipStream_t stream);
+                              int d_valid, const int64_t* st, hipStream_t stream);
 hipError_t launch_attn_fwd(const AttnParams& p, int D, int v_dtype, int o_dtype, int causal, hipStream_t stream);
 }  // namespace lbfa
 
@@ -44,6 +44,10 @@ void dense_scale_layout(lbfa::AttnParams& p) {
   p.ksc_b = (int64_t)p.Hkv * p.nK; p.ksc_h = p.nK; p.ksc_blk = 1;
   p.cu_q = p.cu_k = p.cu_qscale = p.cu_kscale = nullptr;
 }
+// head dims the one-call operators take directly: the kernels work on 64 / 128 channels and treat the rest as the
+// zero padding of src/core.py:277-287 (never read, never written)
+bool head_dim_ok(int D) { return D >= 8 && D <= 128 && D % 8 == 0; }
+int padded_head_dim(int D) { return D <= 64 ? 64 : 128; }
 }  // namespace
 
 namespace {
@@ -76,8 +80,9 @@ size_t lbfa_mean_seq_workspace_bytes(int B, int H, int S, int D) {
   return (size_t)B * H * nsplit * D * sizeof(float);
 }
 
-int lbfa_mean_seq(const void* x, int dtype, void* mean_out, void* workspace, size_t workspace_bytes,
-                  int B, int H, int S, int D, const int64_t strides_x[3], void* stream) {
+namespace {
+int mean_impl(const void* x, int dtype, void* mean_out, void* workspace, size_t workspace_bytes,
+              int B, int H, int S, int D, int d_valid, const int64_t strides_x[3], void* stream) {
   if (!x || !mean_out || !workspace || !strides_x) return fail(LBFA_EINVAL, "lbfa_mean_seq: null pointer");
   if (!dims_ok(B, H, S, D)) return fail(LBFA_EINVAL, "Unsupported head_dim: %d (or empty tensor %dx%dx%d)", D, B, H, S);
   if (dtype != LBFA_F16 && dtype != LBFA_BF16)
@@ -86,14 +91,21 @@ int lbfa_mean_seq(const void* x, int dtype, void* mean_out, void* workspace, siz
   if (!aligned16(x) || (strides_x[0] | strides_x[1] | strides_x[2]) % 8 != 0)
     return fail(LBFA_EINVAL, "lbfa_mean_seq: x must be 16-byte aligned with strides that are multiples of 8 elements");
   g_err[0] = 0;
-  return check_hip(lbfa::launch_mean_seq(x, dtype, mean_out, workspace, B, H, S, D, strides_x, (hipStream_t)stream),
+  return check_hip(lbfa::launch_mean_seq(x, dtype, mean_out, workspace, B, H, S, D, d_valid, strides_x, (hipStream_t)stream),
                    "lbfa_mean_seq launch");
 }
+}  // namespace
 
-int lbfa_quant_per_block(const void* x, int dtype, const void* mean, int mean_group, int8_t* out, float* scale,
-                         float sm_scale, int qmax, int blk, int B, int H, int S, int D,
-                         const int64_t strides_x[3], const int64_t strides_out[3],
-                         const void* rowdot_vec, int rowdot_group, float* rowdot_out, void* stream) {
+int lbfa_mean_seq(const void* x, int dtype, void* mean_out, void* workspace, size_t workspace_bytes,
+                  int B, int H, int S, int D, const int64_t strides_x[3], void* stream) {
+  return mean_impl(x, dtype, mean_out, workspace, workspace_bytes, B, H, S, D, D, strides_x, stream);
+}
+
+namespace {
+int quant_impl(const void* x, int dtype, const void* mean, int mean_group, int8_t* out, float* scale,
+               float sm_scale, int qmax, int blk, int B, int H, int S, int D, int d_valid,
+               const int64_t strides_x[3], const int64_t strides_out[3],
+               const void* rowdot_vec, int rowdot_group, float* rowdot_out, void* stream) {
   if (!x || !out || !scale || !strides_x || !strides_out) return fail(LBFA_EINVAL, "lbfa_quant_per_block: null pointer");
   if (!dims_ok(B, H, S, D)) return fail(LBFA_EINVAL, "Unsupported head_dim: %d (or empty tensor %dx%dx%d)", D, B, H, S);
   if (dtype != LBFA_F16 && dtype != LBFA_BF16)
@@ -124,15 +136,26 @@ int lbfa_quant_per_block(const void* x, int dtype, const void* mean, int mean_gr
   p.rowdot_group = rowdot_vec ? rowdot_group : 1;
   p.scale_b = (int64_t)H * p.nblk; p.scale_h = p.nblk; p.scale_blk = 1;
   p.cu_seqlens = nullptr; p.cu_scale = nullptr; p.mean_b = 1;
+  p.d_valid = d_valid;
   g_err[0] = 0;
   return check_hip(lbfa::launch_quant_per_block(p, dtype, D, blk, (hipStream_t)stream), "lbfa_quant_per_block launch");
+}
+}  // namespace
+
+int lbfa_quant_per_block(const void* x, int dtype, const void* mean, int mean_group, int8_t* out, float* scale,
+                         float sm_scale, int qmax, int blk, int B, int H, int S, int D,
+                         const int64_t strides_x[3], const int64_t strides_out[3],
+                         const void* rowdot_vec, int rowdot_group, float* rowdot_out, void* stream) {
+  return quant_impl(x, dtype, mean, mean_group, out, scale, sm_scale, qmax, blk, B, H, S, D, D, strides_x, strides_out,
+                    rowdot_vec, rowdot_group, rowdot_out, stream);
 }
 
 namespace {
 // packed batch, shared by lbfa_quant_per_block_varlen (reference scale layout) and lbfa_forward_varlen (padded layout)
 int quant_varlen_core(const char* who, const void* x, int dtype, const void* mean, int mean_group, int8_t* out, float* scale,
                       const int32_t* cu_seqlens, const int32_t* cu_scale, float sm_scale, int qmax, int blk, int B,
-                      int max_seqlen, int H, int D, const int64_t strides_x[2], const int64_t strides_out[2], void* stream) {
+                      int max_seqlen, int H, int D, int d_valid, const int64_t strides_x[2], const int64_t strides_out[2],
+                      void* stream) {
   if (!x || !out || !scale || !cu_seqlens || !strides_x || !strides_out) return fail(LBFA_EINVAL, "%s: null pointer", who);
   if (!dims_ok(B, H, max_seqlen, D)) return fail(LBFA_EINVAL, "Unsupported head_dim: %d (or empty batch %dx%dx%d)", D, B, H, max_seqlen);
   if (dtype != LBFA_F16 && dtype != LBFA_BF16)
@@ -162,6 +185,7 @@ int quant_varlen_core(const char* who, const void* x, int dtype, const void* mea
   if (cu_scale) { p.scale_b = H; p.scale_h = 1; p.scale_blk = H; }              // [sum_blocks, H]
   else { p.scale_b = (int64_t)H * p.nblk; p.scale_h = p.nblk; p.scale_blk = 1; }  // [B, H, max_blocks]
   p.cu_seqlens = cu_seqlens; p.cu_scale = cu_scale; p.mean_b = 0;
+  p.d_valid = d_valid;
   g_err[0] = 0;
   return check_hip(lbfa::launch_quant_per_block(p, dtype, D, blk, (hipStream_t)stream), who);
 }
@@ -173,7 +197,7 @@ int lbfa_quant_per_block_varlen(const void* x, int dtype, const void* mean, int 
                                 const int64_t strides_out[2], void* stream) {
   if (!cu_seqlens_scale) return fail(LBFA_EINVAL, "lbfa_quant_per_block_varlen: null pointer");
   return quant_varlen_core("lbfa_quant_per_block_varlen", x, dtype, mean, mean_group, out, scale, cu_seqlens, cu_seqlens_scale,
-                           sm_scale, qmax, blk, B, max_seqlen, H, D, strides_x, strides_out, stream);
+                           sm_scale, qmax, blk, B, max_seqlen, H, D, D, strides_x, strides_out, stream);
 }
 
 size_t lbfa_v_fp8_bytes(int B, int H, int S, int D) {
@@ -182,7 +206,8 @@ size_t lbfa_v_fp8_bytes(int B, int H, int S, int D) {
   return lbfa::v_fp8_payload_bytes(B, H, S, D) + (size_t)B * H * D * sizeof(float);
 }
 
-int lbfa_quant_v_fp8(const void* v, int dtype, uint8_t* v_fp8, float* v_scale, int B, int H, int S, int D,
+namespace {
+int quant_v_fp8_impl(const void* v, int dtype, uint8_t* v_fp8, float* v_scale, int B, int H, int S, int D, int d_valid,
                      const int64_t strides_v[3], void* stream) {
   if (!v || !v_fp8 || !v_scale || !strides_v) return fail(LBFA_EINVAL, "lbfa_quant_v_fp8: null pointer");
   if (!dims_ok(B, H, S, D)) return fail(LBFA_EINVAL, "Unsupported head_dim: %d (or empty tensor %dx%dx%d)", D, B, H, S);
@@ -191,8 +216,14 @@ int lbfa_quant_v_fp8(const void* v, int dtype, uint8_t* v_fp8, float* v_scale, i
   if (!aligned16(v) || !aligned16(v_fp8) || (strides_v[0] | strides_v[1] | strides_v[2]) % 8 != 0)
     return fail(LBFA_EINVAL, "lbfa_quant_v_fp8: v / v_fp8 must be 16-byte aligned, strides multiples of 8 elements");
   g_err[0] = 0;
-  return check_hip(lbfa::launch_quant_v_fp8(v, dtype, v_fp8, v_scale, B, H, S, D, strides_v, (hipStream_t)stream),
+  return check_hip(lbfa::launch_quant_v_fp8(v, dtype, v_fp8, v_scale, B, H, S, D, d_valid, strides_v, (hipStream_t)stream),
                    "lbfa_quant_v_fp8 launch");
+}
+}  // namespace
+
+int lbfa_quant_v_fp8(const void* v, int dtype, uint8_t* v_fp8, float* v_scale, int B, int H, int S, int D,
+                     const int64_t strides_v[3], void* stream) {
+  return quant_v_fp8_impl(v, dtype, v_fp8, v_scale, B, H, S, D, D, strides_v, stream);
 }
 
 int lbfa_attn_fwd(const int8_t* q, const int8_t* k, const void* v, int v_dtype, void* o, int o_dtype, float* lse,
@@ -243,6 +274,7 @@ int lbfa_attn_fwd(const int8_t* q, const int8_t* k, const void* v, int v_dtype, 
   p.lse_scale = 1.0f;
   p.lse_corr_scale = 0.0f;
   dense_scale_layout(p);
+  p.d_valid = D;
   if ((int64_t)B * Hq * p.nQ > 0x7fffffffLL) return fail(LBFA_EINVAL, "lbfa_attn_fwd: grid too large");
   g_err[0] = 0;
   return check_hip(launch_attention(p, D, v_dtype, o_dtype, is_causal ? 1 : 0, (hipStream_t)stream), "lbfa_attn_fwd launch");
@@ -276,8 +308,8 @@ FwdLayout fwd_layout(int B, int Hq, int Hkv, int Sq, int Sk, int D, int pv_fp8, 
 }  // namespace
 
 size_t lbfa_forward_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int pv_fp8, int smooth_k, int return_lse) {
-  if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Sk <= 0 || D <= 0) return 0;
-  return fwd_layout(B, Hq, Hkv, Sq, Sk, D, pv_fp8, smooth_k && return_lse).total;
+  if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Sk <= 0 || !head_dim_ok(D)) return 0;
+  return fwd_layout(B, Hq, Hkv, Sq, Sk, padded_head_dim(D), pv_fp8, smooth_k && return_lse).total;
 }
 
 int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o, float* lse, void* workspace,
@@ -285,10 +317,12 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
                  const int64_t strides_q[3], const int64_t strides_k[3], const int64_t strides_v[3],
                  const int64_t strides_o[3], float sm_scale, int q_qmax, int k_qmax, int pv_fp8, int is_causal,
                  int smooth_k, void* stream) {
+  const int Dg = D;  // head dim of the caller's tensors
   if (!q || !k || !v || !o || !workspace || !strides_q || !strides_k || !strides_v || !strides_o)
     return fail(LBFA_EINVAL, "lbfa_forward: null pointer");
   if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Sk <= 0) return fail(LBFA_EINVAL, "lbfa_forward: empty tensor");
-  if (D != 64 && D != 128) return fail(LBFA_EINVAL, "Unsupported head_dim: %d", D);
+  if (!head_dim_ok(Dg)) return fail(LBFA_EINVAL, "Unsupported head_dim: %d", Dg);
+  D = padded_head_dim(Dg);  // what the kernels run on; channels >= Dg are never read or written
   if (Hq % Hkv != 0) return fail(LBFA_EINVAL, "num_qo_heads (%d) must be divisible by num_kv_heads (%d)", Hq, Hkv);
   const int want_lse = lse != nullptr, want_corr = want_lse && smooth_k;
   const FwdLayout L = fwd_layout(B, Hq, Hkv, Sq, Sk, D, pv_fp8, want_corr);
@@ -305,20 +339,20 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
   const int64_t sk8[3] = {(int64_t)Hkv * Sk * D, (int64_t)Sk * D, D};
   int st;
   if (smooth_k) {
-    st = lbfa_mean_seq(k, dtype, km, ws + L.part, lbfa_mean_seq_workspace_bytes(B, Hkv, Sk, D), B, Hkv, Sk, D, strides_k, stream);
+    st = mean_impl(k, dtype, km, ws + L.part, lbfa_mean_seq_workspace_bytes(B, Hkv, Sk, D), B, Hkv, Sk, D, Dg, strides_k, stream);
     if (st) return st;
   }
   // Q: sm_scale * log2(e) folded into the codes' scale (src/triton/quant_per_block.py:226); lse_correction = q . km
-  st = lbfa_quant_per_block(q, dtype, nullptr, 1, q8, qs, sm_scale * 1.44269504f, q_qmax, LBFA_BLKQ, B, Hq, Sq, D, strides_q, sq8,
-                            want_corr ? km : nullptr, Hq / Hkv, corr, stream);
+  st = quant_impl(q, dtype, nullptr, 1, q8, qs, sm_scale * 1.44269504f, q_qmax, LBFA_BLKQ, B, Hq, Sq, D, Dg, strides_q, sq8,
+                  want_corr ? km : nullptr, Hq / Hkv, corr, stream);
   if (st) return st;
-  st = lbfa_quant_per_block(k, dtype, km, 1, k8, ks, 1.0f, k_qmax, LBFA_BLKK, B, Hkv, Sk, D, strides_k, sk8, nullptr, 1, nullptr, stream);
+  st = quant_impl(k, dtype, km, 1, k8, ks, 1.0f, k_qmax, LBFA_BLKK, B, Hkv, Sk, D, Dg, strides_k, sk8, nullptr, 1, nullptr, stream);
   if (st) return st;
   const void* v_in = v;
   int v_dtype = dtype;
   const float* v_scale = nullptr;
   if (pv_fp8) {
-    st = lbfa_quant_v_fp8(v, dtype, (uint8_t*)(ws + L.v8), (float*)(ws + L.vs), B, Hkv, Sk, D, strides_v, stream);
+    st = quant_v_fp8_impl(v, dtype, (uint8_t*)(ws + L.v8), (float*)(ws + L.vs), B, Hkv, Sk, D, Dg, strides_v, stream);
     if (st) return st;
     v_in = ws + L.v8;
     v_dtype = LBFA_E4M3;
@@ -352,6 +386,7 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
   p.lse_scale = 1.0f / 1.44269504f;   // natural-log LSE (src/core.py:347)
   p.lse_corr_scale = sm_scale;
   dense_scale_layout(p);
+  p.d_valid = Dg;
   if ((int64_t)B * Hq * p.nQ > 0x7fffffffLL) return fail(LBFA_EINVAL, "lbfa_forward: grid too large");
   g_err[0] = 0;
   return check_hip(launch_attention(p, D, v_dtype, dtype, is_causal ? 1 : 0, (hipStream_t)stream), "lbfa_forward launch");
@@ -365,7 +400,7 @@ namespace {
 int attn_varlen_core(const char* who, const int8_t* q, const int8_t* k, const void* v, int v_dtype, void* o, int o_dtype,
                      const float* q_scale, const float* k_scale, const int32_t* cu_q, const int32_t* cu_k,
                      const int32_t* cu_qscale, const int32_t* cu_kscale, int B, int Hq, int Hkv, int max_q, int max_k, int D,
-                     const int64_t sq[2], const int64_t sk[2], const int64_t sv[2], const int64_t so[2], int is_causal,
+                     int d_valid, const int64_t sq[2], const int64_t sk[2], const int64_t sv[2], const int64_t so[2], int is_causal,
                      void* stream) {
   if (!q || !k || !v || !o || !q_scale || !k_scale || !cu_q || !cu_k || !sq || !sk || !sv || !so)
     return fail(LBFA_EINVAL, "%s: null pointer", who);
@@ -404,6 +439,7 @@ int attn_varlen_core(const char* who, const int8_t* q, const int8_t* k, const vo
     p.ksc_b = Hkv; p.ksc_h = 1; p.ksc_blk = Hkv;    // [sum_k_blocks, Hkv]
   }
   p.cu_q = cu_q; p.cu_k = cu_k; p.cu_qscale = cu_qscale; p.cu_kscale = cu_kscale;
+  p.d_valid = d_valid;
   if ((int64_t)B * Hq * p.nQ > 0x7fffffffLL) return fail(LBFA_EINVAL, "%s: grid too large", who);
   g_err[0] = 0;
   return check_hip(launch_attention(p, D, v_dtype, o_dtype, is_causal ? 1 : 0, (hipStream_t)stream), who);
@@ -435,14 +471,14 @@ int lbfa_attn_fwd_varlen(const int8_t* q, const int8_t* k, const void* v, int v_
                          const int64_t strides_o[2], int is_causal, void* stream) {
   if (!cu_seqlens_q_scale || !cu_seqlens_k_scale) return fail(LBFA_EINVAL, "lbfa_attn_fwd_varlen: null pointer");
   return attn_varlen_core("lbfa_attn_fwd_varlen", q, k, v, v_dtype, o, o_dtype, q_scale, k_scale, cu_seqlens_q, cu_seqlens_k,
-                          cu_seqlens_q_scale, cu_seqlens_k_scale, B, Hq, Hkv, max_seqlen_q, max_seqlen_k, D, strides_q, strides_k,
+                          cu_seqlens_q_scale, cu_seqlens_k_scale, B, Hq, Hkv, max_seqlen_q, max_seqlen_k, D, D, strides_q, strides_k,
                           strides_v, strides_o, is_causal, stream);
 }
 
 size_t lbfa_forward_varlen_workspace_bytes(int B, int Hq, int Hkv, int total_q, int total_k, int max_seqlen_q,
                                            int max_seqlen_k, int D) {
-  if (B <= 0 || Hq <= 0 || Hkv <= 0 || total_q <= 0 || total_k <= 0 || max_seqlen_q <= 0 || max_seqlen_k <= 0 || D <= 0) return 0;
-  return varlen_layout(B, Hq, Hkv, total_q, total_k, max_seqlen_q, max_seqlen_k, D).total;
+  if (B <= 0 || Hq <= 0 || Hkv <= 0 || total_q <= 0 || total_k <= 0 || max_seqlen_q <= 0 || max_seqlen_k <= 0 || !head_dim_ok(D)) return 0;
+  return varlen_layout(B, Hq, Hkv, total_q, total_k, max_seqlen_q, max_seqlen_k, padded_head_dim(D)).total;
 }
 
 int lbfa_forward_varlen(const void* q, const void* k, const void* v, int dtype, void* o,
@@ -451,11 +487,13 @@ int lbfa_forward_varlen(const void* q, const void* k, const void* v, int dtype, 
                         const int64_t strides_q[2], const int64_t strides_k[2], const int64_t strides_v[2],
                         const int64_t strides_o[2], float sm_scale, int q_qmax, int k_qmax, int is_causal, int smooth_k,
                         void* stream) {
+  const int Dg = D;  // head dim of the caller's tensors
   if (!q || !k || !v || !o || !workspace || !cu_seqlens_q || !cu_seqlens_k || !strides_q || !strides_k || !strides_v || !strides_o)
     return fail(LBFA_EINVAL, "lbfa_forward_varlen: null pointer");
   if (B <= 0 || Hq <= 0 || Hkv <= 0 || total_q <= 0 || total_k <= 0 || max_seqlen_q <= 0 || max_seqlen_k <= 0)
     return fail(LBFA_EINVAL, "lbfa_forward_varlen: empty batch");
-  if (D != 64 && D != 128) return fail(LBFA_EINVAL, "Unsupported head_dim: %d", D);
+  if (!head_dim_ok(Dg)) return fail(LBFA_EINVAL, "Unsupported head_dim: %d", Dg);
+  D = padded_head_dim(Dg);
   if (Hq % Hkv != 0) return fail(LBFA_EINVAL, "num_qo_heads (%d) must be divisible by num_kv_heads (%d)", Hq, Hkv);
   const VarlenLayout L = varlen_layout(B, Hq, Hkv, total_q, total_k, max_seqlen_q, max_seqlen_k, D);
   if (workspace_bytes < L.total) return fail(LBFA_EINVAL, "lbfa_forward_varlen: workspace too small (%zu < %zu)", workspace_bytes, L.total);
@@ -471,17 +509,17 @@ int lbfa_forward_varlen(const void* q, const void* k, const void* v, int dtype, 
   int st;
   if (smooth_k) {  // km = k.mean(dim=0): over ALL tokens of the packed batch (src/core.py:453)
     const int64_t sk3[3] = {0, strides_k[0], strides_k[1]};
-    st = lbfa_mean_seq(k, dtype, km, ws + L.part, lbfa_mean_seq_workspace_bytes(1, Hkv, total_k, D), 1, Hkv, total_k, D, sk3, stream);
+    st = mean_impl(k, dtype, km, ws + L.part, lbfa_mean_seq_workspace_bytes(1, Hkv, total_k, D), 1, Hkv, total_k, D, Dg, sk3, stream);
     if (st) return st;
   }
   st = quant_varlen_core("lbfa_forward_varlen (Q)", q, dtype, nullptr, 1, q8, qs, cu_seqlens_q, nullptr, sm_scale * 1.44269504f,
-                         q_qmax, LBFA_BLKQ, B, max_seqlen_q, Hq, D, strides_q, sq8, stream);
+                         q_qmax, LBFA_BLKQ, B, max_seqlen_q, Hq, D, Dg, strides_q, sq8, stream);
   if (st) return st;
   st = quant_varlen_core("lbfa_forward_varlen (K)", k, dtype, km, 1, k8, ks, cu_seqlens_k, nullptr, 1.0f, k_qmax, LBFA_BLKK, B,
-                         max_seqlen_k, Hkv, D, strides_k, sk8, stream);
+                         max_seqlen_k, Hkv, D, Dg, strides_k, sk8, stream);
   if (st) return st;
   return attn_varlen_core("lbfa_forward_varlen", q8, k8, v, dtype, o, dtype, qs, ks, cu_seqlens_q, cu_seqlens_k, nullptr, nullptr,
-                          B, Hq, Hkv, max_seqlen_q, max_seqlen_k, D, sq8, sk8, strides_v, strides_o, is_causal, stream);
+                          B, Hq, Hkv, max_seqlen_q, max_seqlen_k, D, Dg, sq8, sk8, strides_v, strides_o, is_causal, stream);
 }
 
 }  // extern "C"

@@ -85,6 +85,7 @@ struct QuantParams {
   // x / out (batch strides unused), blocks restart at each sequence.  null = dense.
   const int* cu_seqlens;
   const int* cu_scale;
+  int d_valid;  // columns >= d_valid of x are padding: not read, codes 0 (head-dim pad of src/core.py:277-287 without a copy)
   int mean_b;  // 1: mean / rowdot_vec are per batch entry; 0: one vector set shared by all (varlen k.mean(dim=0), :453)
 };
 
@@ -110,6 +111,7 @@ struct AttnParams {
   const int* cu_k;
   const int* cu_qscale;
   const int* cu_kscale;
+  int d_valid;  // channels >= d_valid of V / O are padding: V reads as 0, O is not written (o has d_valid columns)
 };
 
 }  // namespace lbfa

@@ -21,6 +21,7 @@ struct MeanParams {
   void* out;        // [B,H,D] storage dtype
   int64_t sb, sh, ss;
   int B, H, S, D, rows_per_split, nsplit;
+  int d_valid;  // columns >= d_valid are padding: not read, mean 0 (head-dim pad of src/core.py:277-287 without a copy)
 };
 
 template <int DT, int D>
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(256) void mean_partial_kernel(MeanParams p) {
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  if (c * 8 < p.d_valid)
   for (int r = r0 + rl; r < r1; r += RL) {
     const uint4 raw = *reinterpret_cast<const uint4*>(base + (int64_t)r * p.ss);
     const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void quant_per_block_kernel(QuantParams p) {
   for (int ps = 0; ps < NP; ++ps) {
     const int row = blk * BLK + ps * RPP + rl;
     raw[ps] = make_uint4(0, 0, 0, 0);  // masked rows load as 0 (quant_per_block.py:170)
-    if (row < S) raw[ps] = *reinterpret_cast<const uint4*>(xbase + (int64_t)row * p.xs);
+    if (row < S && c * 8 < p.d_valid) raw[ps] = *reinterpret_cast<const uint4*>(xbase + (int64_t)row * p.xs);
   }
   float xs[NP][8];
   float amax = 0.f;
@@ -204,6 +206,7 @@ struct VFp8Params {
   unsigned* amax_bits; // [B,H,D] scratch at the tail of the v_fp8 allocation; zeroed before the launch
   int64_t vb, vh, vs;
   int B, H, S, ntile, rows_per_split;
+  int d_valid;  // channels >= d_valid are padding: not read, encoded as 0
 };
 
 // key permutation inside a 64-key tile: position -> key.  The MFMA B-operand built from the S^T
@@ -230,6 +233,7 @@ __global__ __launch_bounds__(256) void v_amax_kernel(VFp8Params p) {
   float am[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) am[i] = 0.f;
+  if (c * 8 < p.d_valid)
   for (int r = r0 + rl; r < r1; r += RL) {
     const uint4 raw = *reinterpret_cast<const uint4*>(base + (int64_t)r * p.vs);
     const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256) void v_encode_kernel(VFp8Params p) {
     const int key = ps * RPP + rl;
     const int row = tl * 64 + key;
     uint4 raw = make_uint4(0, 0, 0, 0);
-    if (row < p.S) raw = *reinterpret_cast<const uint4*>(base + (int64_t)row * p.vs);
+    if (row < p.S && c * 8 < p.d_valid) raw = *reinterpret_cast<const uint4*>(base + (int64_t)row * p.vs);
     const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
     const int pos = vfp8_pos_of_key(key);
 #pragma unroll
@@ -302,9 +306,10 @@ namespace lbfa {
 
 int mean_rows_per_split(int S) { return S <= 16384 ? 256 : 1024; }
 
-hipError_t launch_mean_seq(const void* x, int dtype, void* out, void* ws, int B, int H, int S, int D,
+hipError_t launch_mean_seq(const void* x, int dtype, void* out, void* ws, int B, int H, int S, int D, int d_valid,
                            const int64_t* st, hipStream_t stream) {
   MeanParams p;
+  p.d_valid = d_valid;
   p.x = (const unsigned short*)x;
   p.partial = (float*)ws;
   p.out = out;
@@ -353,8 +358,9 @@ hipError_t launch_quant_per_block(const QuantParams& p, int dtype, int D, int bl
 size_t v_fp8_payload_bytes(int B, int H, int S, int D) { return (size_t)B * H * ((S + 63) / 64) * D * 64; }
 
 hipError_t launch_quant_v_fp8(const void* v, int dtype, uint8_t* out, float* v_scale, int B, int H, int S, int D,
-                              const int64_t* st, hipStream_t stream) {
+                              int d_valid, const int64_t* st, hipStream_t stream) {
   VFp8Params p;
+  p.d_valid = d_valid;
   p.v = (const unsigned short*)v; p.out = out; p.v_scale = v_scale;
   p.amax_bits = reinterpret_cast<unsigned*>(out + v_fp8_payload_bytes(B, H, S, D));
   p.vb = st[0]; p.vh = st[1]; p.vs = st[2];

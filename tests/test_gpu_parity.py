@@ -373,3 +373,32 @@ def test_one_call_forward_equals_modular_entry_points(oracle, dev, layout, causa
     assert torch.equal(o, o2)
     lse_host = lse2 / 1.44269504 + corr * sm_scale
     assert float((lse - lse_host).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("D,layout,causal,pv", [
+    (40, "HND", False, "fp16"), (72, "NHD", True, "fp16"), (96, "HND", True, "fp16"), (120, "NHD", False, "fp16"),
+    (96, "HND", False, "fp8"), (48, "NHD", True, "fp8"),
+    (36, "HND", False, "fp16"),   # not a multiple of 8: padded on the host as the reference does
+])
+def test_head_dims_padded_inside_the_kernels(oracle, dev, D, layout, causal, pv):
+    """Head dims other than 64 / 128 (src/core.py:277-287 pads q, k, v with zeros and slices o): multiples of 8 are
+    handled inside the kernels (padding channels are never read or written) and must give the padded result."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    B, H, Hkv, S = 2, 4, 2, 200
+    q, k, v = oracle.make_inputs(B, H, S, D, seed=17, layout=layout, Hkv=Hkv, k_bias=0.3)
+    tq, tk, tv = (_t(a, "fp16", dev) for a in (q, k, v))
+    fn = lb.lowbit_fa_qk_int8_pv_fp16_triton if pv == "fp16" else lb.lowbit_fa_qk_int8_pv_fp8_cuda
+    o, lse = fn(tq, tk, tv, tensor_layout=layout, is_causal=causal, return_lse=True)
+    assert tuple(o.shape) == q.shape
+    ro, rlse = oracle.lowbit_fa_forward(q, k, v, tensor_layout=layout, is_causal=causal, return_lse=True, pv=pv,
+                                        tail="neg_inf", amax_floor=1e-7)
+    if pv == "fp16":
+        _o_close(_np(o), ro, "fp16")
+    else:
+        assert float(np.mean((_np(o) - ro) ** 2)) <= 1e-4
+    assert np.abs(_np(lse) - rlse).max() <= 2e-3
+    # identical to explicit zero padding on the host
+    pad = (64 if D < 64 else 128) - D
+    pq, pk, pv_ = (torch.nn.functional.pad(t, (0, pad)) for t in (tq, tk, tv))
+    o_p = fn(pq, pk, pv_, tensor_layout=layout, is_causal=causal, sm_scale=D ** -0.5)[..., :D]
+    assert torch.equal(o, o_p)

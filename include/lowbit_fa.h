@@ -160,6 +160,19 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
                  int smooth_k, void* stream);
 
 /*
+ * Un-quantised FlashAttention-2 forward, O = softmax(Q K^T * sm_scale) V, on the same tiling as lbfa_attn_fwd with
+ * fp16 MFMAs for both products (bf16 inputs are converted to fp16 on the way into LDS / registers, fp32 softmax and
+ * accumulation).  This is the "FP16" branch of the precision router `sageattn_multi_precision`
+ * (src/core.py:1066-1096), which the reference sends to `default_attn` (:46-69 / the framework's SDPA).
+ *   q [B,Hq,Sq,D], k / v [B,Hkv,Sk,D], o like q: one dtype (LBFA_F16 / LBFA_BF16), strides {batch, head, seq}.
+ *   D: any multiple of 8 up to 128 (as lbfa_forward).  lse: NULL or [B,Hq,Sq] fp32 natural-log LSE.
+ */
+int lbfa_sdpa_fwd(const void* q, const void* k, const void* v, int dtype, void* o, float* lse,
+                  int B, int Hq, int Hkv, int Sq, int Sk, int D,
+                  const int64_t strides_q[3], const int64_t strides_k[3], const int64_t strides_v[3],
+                  const int64_t strides_o[3], float sm_scale, int is_causal, void* stream);
+
+/*
  * Packed variable-length batches (reference: `sageattn_varlen`, src/core.py:356-491).
  *   q [total_q, Hq, D], k / v [total_k, Hkv, D]; sequence b owns tokens [cu_seqlens[b], cu_seqlens[b+1]);
  *   cu_seqlens_* are int32 device arrays of B + 1 entries; strides are in elements {head, token}.

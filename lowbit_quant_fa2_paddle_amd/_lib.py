@@ -42,6 +42,9 @@ SIGNATURES = {
                            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                            _cf, _ci, _ci, _ci, _ci, _ci, _vp]),
+    "lbfa_sdpa_fwd": (_ci, [_vp, _vp, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci,
+                            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), _cf, _ci, _vp]),
     "lbfa_quant_per_block_varlen": (_ci, [_vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _cf, _ci, _ci, _ci, _ci, _ci, _ci,
                                           ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), _vp]),
     "lbfa_attn_fwd_varlen": (_ci, [_vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -237,7 +237,45 @@ def manual_scaled_dot_product_attention(q, k, v, is_causal=False):
     return torch.matmul(torch.softmax(scores, dim=-1), v)
 
 
-default_attn = manual_scaled_dot_product_attention
+def flash_attn_fp16(q, k, v, tensor_layout: str = "HND", is_causal: bool = False, sm_scale: Optional[float] = None,
+                    return_lse: bool = False, **kwargs: Any):
+    """Un-quantised FlashAttention-2 forward on the HIP back end (`lbfa_sdpa_fwd`): fp16 MFMAs for QK^T and PV, fp32
+    softmax - the kernel behind the "FP16" branch of `sageattn_multi_precision` (the reference calls the framework's
+    SDPA / `manual_scaled_dot_product_attention` there, src/core.py:46-69,1086-1087).  Same layouts, GQA, head dims
+    and return convention as the low-bit operators; bf16 inputs are converted to fp16 inside the kernel."""
+    ops, dtype = _check_inputs(q, k, v)
+    if tensor_layout not in ("HND", "NHD"):
+        raise ValueError(f"Unknown tensor layout: {tensor_layout}")
+    qshape = ops.shape(q)
+    if 0 in qshape:
+        o = ops.empty(qshape, dtype, q)
+        hdim = 1 if tensor_layout == "HND" else 2
+        return (o, ops.empty((qshape[0], qshape[hdim], qshape[3 - hdim]), ops.float32, q)) if return_lse else o
+    if 0 in ops.shape(k):
+        raise ValueError("k/v must hold at least one key (softmax over an empty set is undefined)")
+    q, k, v, head_dim_og = _pad_head_dim(ops, q, k, v)
+    if sm_scale is None:
+        sm_scale = 1.0 / head_dim_og ** 0.5
+    lib = _lib.load()
+    qshape = ops.shape(q)
+    (B, Hq, Sq), q3 = _qpb._bhs(qshape, ops.strides(q), tensor_layout)
+    (_, Hkv, Sk), k3 = _qpb._bhs(ops.shape(k), ops.strides(k), tensor_layout)
+    (_, _, _), v3 = _qpb._bhs(ops.shape(v), ops.strides(v), tensor_layout)
+    if is_causal and Sq != Sk:
+        raise AssertionError("qo_len and kv_len must be equal for causal attention")
+    o = ops.empty(qshape, dtype, q)
+    (_, _, _), o3 = _qpb._bhs(qshape, ops.strides(o), tensor_layout)
+    lse = ops.empty((B, Hq, Sq), ops.float32, q) if return_lse else None
+    with ops.device_guard(q):
+        _lib.check(lib.lbfa_sdpa_fwd(ops.ptr(q), ops.ptr(k), ops.ptr(v), ops.dtype_code(q), ops.ptr(o),
+                                     ops.ptr(lse) if return_lse else None, B, Hq, Hkv, Sq, Sk, qshape[3],
+                                     _lib.strides3(q3), _lib.strides3(k3), _lib.strides3(v3), _lib.strides3(o3),
+                                     float(sm_scale), 1 if is_causal else 0, ops.stream(q)), lib)
+    o = o[..., :head_dim_og]
+    return (o, lse) if return_lse else o
+
+
+default_attn = flash_attn_fp16
 
 
 def compute_scale(tensor, bits=8, symmetric=True):
@@ -262,7 +300,7 @@ def sageattn_multi_precision(q, k, v, tensor_layout: str = "HND", is_causal: boo
     """Importance-aware precision router (reference: src/core.py:1066-1096)."""
     kind = select_quantization(q, k, v)
     if kind == "FP16":
-        return default_attn(q, k, v, is_causal=is_causal)
+        return default_attn(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal, sm_scale=sm_scale, return_lse=return_lse)
     if kind == "INT8":
         return sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal,
                                                sm_scale=sm_scale, return_lse=return_lse)

@@ -16,10 +16,11 @@ __device__ __forceinline__ f16x4 lds_read_tr16(const char* addr) {
   return __builtin_bit_cast(f16x4, v);
 }
 
-template <int D>
-__device__ __forceinline__ int kx(int row) {  // K-tile chunk swizzle
-  if constexpr (D == 64) return (row >> 2) & 3;
-  else return (row >> 1) & 7;
+template <int RB>
+__device__ __forceinline__ int kx(int row) {  // K-tile 16-B chunk swizzle for rows of RB bytes (int8: RB = D, fp16: 2 D)
+  if constexpr (RB == 64) return (row >> 2) & 3;
+  else if constexpr (RB == 128) return (row >> 1) & 7;
+  else return row & 15;
 }
 template <int D>
 __device__ __forceinline__ int vx(int row) {  // V-tile 64-B chunk swizzle
@@ -58,5 +59,17 @@ __device__ __forceinline__ void static_for(F&& f) {
 constexpr float kFp8Offset = 8.807f;  // csrc/qattn/attn_utils.cuh:30: p = exp2(s - m + 8.807) -> p_max = 448
 constexpr float kMagic = 12582912.0f;  // 1.5 * 2^23: int32 accumulator bits == float(kMagic + s) for |s| < 2^22
 constexpr int kMagicBits = 0x4B400000;
+constexpr int kQInt8 = 3;  // QT of the attention kernel: int8 codes; LBFA_F16 / LBFA_BF16 = un-quantised Q and K
+
+// bf16 pairs -> fp16 pairs, in place (a 16-byte chunk = 8 elements)
+__device__ __forceinline__ u32x4 bf16x8_to_f16x8(u32x4 val) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float lo = __uint_as_float(val[e] << 16), hi = __uint_as_float(val[e] & 0xffff0000u);
+    const f16x2 pk = f16x2{(_Float16)lo, (_Float16)hi};
+    val[e] = __builtin_bit_cast(unsigned, pk);
+  }
+  return val;
+}
 
 }  // namespace lbfa

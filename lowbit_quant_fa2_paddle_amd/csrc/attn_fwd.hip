@@ -60,14 +60,20 @@ __device__ __forceinline__ float ones_rowsum(const PF (&pf)[4]) {
   }
 }
 
-template <int D, int VT, int OT, bool CAUSAL>
+template <int D, int QT, int VT, int OT, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   constexpr bool FP8 = (VT == LBFA_E4M3);
+  // QT = kQInt8: the low-bit path.  QT = LBFA_F16 / LBFA_BF16: un-quantised Q and K (the FP16 branch of the
+  // precision router, src/core.py:1066-1096): same tiling and softmax, scores from v_mfma_f32_32x32x16_f16 on fp16
+  // tiles (bf16 is converted on the way in, like V), K rows are 2 D bytes.
+  constexpr bool QK16 = (QT != kQInt8);
+  constexpr int ESZ = QK16 ? 2 : 1;                  // bytes per Q / K element
+  constexpr int RB = D * ESZ;                        // bytes per K row
   // fp8 P is scaled so that its maximum is 448 = e4m3 max (attn_utils.cuh:30): no headroom to defer
   constexpr float THR = FP8 ? 0.0f : LBFA_THR;
-  constexpr int KS = D / 32;                         // int8 k-steps of the score product
+  constexpr int KS = RB / 32;                        // k-steps of the score product (32 int8 or 16 fp16 per MFMA)
   constexpr int DB = D / 32;                         // 32-channel blocks of O^T
-  constexpr int KBYTES = 64 * D;                     // K tile
+  constexpr int KBYTES = 64 * RB;                    // K tile
   constexpr int VBYTES = FP8 ? 64 * D : 128 * D;     // V tile
   constexpr int KCH = KBYTES / (256 * 16);           // 16-B chunks per thread
   constexpr int VCH = VBYTES / (256 * 16);
@@ -114,10 +120,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 
   // ---- operand windows (bytes).  The descriptor is re-based per tile with scalar arithmetic, so the
   // hardware range check sees only the loop-invariant per-lane offset.
-  const char* qbase = (const char*)p.q + q_off + (int64_t)h * p.qh;
-  const char* kbase = (const char*)p.k + k_off + (int64_t)hk * p.kh;
-  const int64_t k_bytes = (int64_t)(Sk - 1) * p.ks + D;
-  const int64_t k_tile_stride = 64 * p.ks;
+  const int dq_valid = QK16 ? p.d_valid : D;  // un-quantised Q / K come from the caller's tensors: head-dim padding applies
+  const char* qbase = (const char*)p.q + ESZ * (q_off + (int64_t)h * p.qh);
+  const char* kbase = (const char*)p.k + ESZ * (k_off + (int64_t)hk * p.kh);
+  const int64_t k_bytes = ESZ * ((int64_t)(Sk - 1) * p.ks + dq_valid);
+  const int64_t k_tile_stride = ESZ * 64 * p.ks;
   const char* vbase;
   int64_t v_bytes, v_tile_stride;  // bytes between consecutive 64-key tiles
   if constexpr (FP8) {
@@ -129,16 +136,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     v_bytes = 2 * ((int64_t)(Sk - 1) * p.vs + p.d_valid);
     v_tile_stride = 128 * p.vs;
   }
-  const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(qbase, (unsigned)((int64_t)(Sq - 1) * p.qs + D));
+  const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(qbase, (unsigned)(ESZ * ((int64_t)(Sq - 1) * p.qs + dq_valid)));
 
-  // ---- Q fragments (B operand of the int8 MFMA): lane (r, hh) holds bytes [32s+16hh, +16) of its row.
+  // ---- Q fragments (B operand of the score MFMA): lane (r, hh) holds bytes [32s+16hh, +16) of its row.
   // Rows >= Sq are out of the descriptor's range and read as zeros.
   i32x4 qf[KS];
 #pragma unroll
-  for (int s = 0; s < KS; ++s)
-    qf[s] = __builtin_bit_cast(i32x4, buf_load16(q_rs, (unsigned)qrow * (unsigned)p.qs + 16 * hh + 32 * s, 0));
-  const float qsc = p.q_scale[qsc_base + (int64_t)h * p.qsc_h + (int64_t)qt * p.qsc_blk];
-  const float* ksc = p.k_scale + ksc_base + (int64_t)hk * p.ksc_h;
+  for (int s = 0; s < KS; ++s) {
+    const unsigned col_b = 16 * hh + 32 * s;  // byte column
+    u32x4 raw = buf_load16(q_rs, col_b < (unsigned)(ESZ * dq_valid) ? ESZ * (unsigned)qrow * (unsigned)p.qs + col_b : 0x80000000u, 0);
+    if constexpr (QT == LBFA_BF16) raw = bf16x8_to_f16x8(raw);
+    qf[s] = __builtin_bit_cast(i32x4, raw);
+  }
+  float qsc = 1.0f;
+  const float* ksc = nullptr;
+  if constexpr (!QK16) {
+    qsc = p.q_scale[qsc_base + (int64_t)h * p.qsc_h + (int64_t)qt * p.qsc_blk];
+    ksc = p.k_scale + ksc_base + (int64_t)hk * p.ksc_h;
+  }
   const int ksc_blk = (int)p.ksc_blk;
 
   int n_tiles = nK;
@@ -148,9 +163,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   unsigned k_goff[KCH], k_loff[KCH], v_goff[VCH], v_loff[VCH];
 #pragma unroll
   for (int i = 0; i < KCH; ++i) {
-    const int c = t + 256 * i, row = c / (D / 16), ch = c % (D / 16);
-    k_goff[i] = (unsigned)row * (unsigned)p.ks + ch * 16;
-    k_loff[i] = row * D + ((ch ^ kx<D>(row)) << 4);
+    const int c = t + 256 * i, row = c / (RB / 16), ch = c % (RB / 16);
+    k_goff[i] = ch * 16 < ESZ * dq_valid ? ESZ * (unsigned)row * (unsigned)p.ks + ch * 16 : 0x80000000u;
+    k_loff[i] = row * RB + ((ch ^ kx<RB>(row)) << 4);
   }
 #pragma unroll
   for (int i = 0; i < VCH; ++i) {
@@ -167,9 +182,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   // Fragment read addresses.  The swizzles depend only on the low row bits, so the block / k-step / high-half /
   // buffer parts are compile-time byte offsets folded into the ds_read immediates; per lane only KS (K) and
   // DB or 4 (V) base registers are needed.
-  unsigned kf_base[KS];  // + kb2 * 32 * D
+  unsigned kf_base[KS];  // + kb2 * 32 * RB
 #pragma unroll
-  for (int s = 0; s < KS; ++s) kf_base[s] = r * D + (((2 * s + hh) ^ kx<D>(r)) << 4);
+  for (int s = 0; s < KS; ++s) kf_base[s] = r * RB + (((2 * s + hh) ^ kx<RB>(r)) << 4);
   constexpr int NVB = FP8 ? 4 : DB;
   unsigned vf_base[NVB];  // f16: [db] + ks*16*2D + hi*8*2D ;  fp8: [ks] + db*32*64
 #pragma unroll
@@ -197,18 +212,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   auto store_tile = [&](auto buf_tag) {
     constexpr int BUF = decltype(buf_tag)::value;
 #pragma unroll
-    for (int i = 0; i < KCH; ++i) *reinterpret_cast<u32x4*>(smem + k_loff[i] + BUF * KBYTES) = kreg[i];
+    for (int i = 0; i < KCH; ++i) {
+      u32x4 val = kreg[i];
+      if constexpr (QT == LBFA_BF16) val = bf16x8_to_f16x8(val);
+      *reinterpret_cast<u32x4*>(smem + k_loff[i] + BUF * KBYTES) = val;
+    }
 #pragma unroll
     for (int i = 0; i < VCH; ++i) {
       u32x4 val = vreg[i];
-      if constexpr (VT == LBFA_BF16) {  // bf16 -> fp16 on the way in (src/core.py:307-308 `v.to(float16)`)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float lo = __uint_as_float(val[e] << 16), hi = __uint_as_float(val[e] & 0xffff0000u);
-          const f16x2 pk = f16x2{(_Float16)lo, (_Float16)hi};
-          val[e] = __builtin_bit_cast(unsigned, pk);
-        }
-      }
+      if constexpr (VT == LBFA_BF16) val = bf16x8_to_f16x8(val);  // bf16 -> fp16 on the way in (src/core.py:307-308 `v.to(float16)`)
       *reinterpret_cast<u32x4*>(smem + v_loff[i] + BUF * VBYTES) = val;
     }
   };
@@ -237,8 +249,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   // - which may be ANY value near the row max - is kept on the same grid (rounded up by < G <= 2^-9 for
   // typical data).  |c1| <= 1.17*kMagic*sc_max < 2^21*G, so every constant is an exact multiple of G.
   float ks_max = 0.f;
-  for (int i = lane; i < nK; i += 64) ks_max = fmaxf(ks_max, ksc[i * ksc_blk]);
-  ks_max = __builtin_amdgcn_readfirstlane(__float_as_uint(wave_max(ks_max))) ? wave_max(ks_max) : 1e-30f;
+  if constexpr (!QK16) {
+    for (int i = lane; i < nK; i += 64) ks_max = fmaxf(ks_max, ksc[i * ksc_blk]);
+    ks_max = __builtin_amdgcn_readfirstlane(__float_as_uint(wave_max(ks_max))) ? wave_max(ks_max) : 1e-30f;
+  }
   const float sc_max = qsc * ks_max;
   const int gexp = (int)((__float_as_uint(1.25f * kMagic * sc_max) >> 23) & 0xff) - 127 + 1 - 21;  // log2(G)
   const float G = __builtin_ldexpf(1.0f, gexp), invG = __builtin_ldexpf(1.0f, -gexp);
@@ -254,8 +268,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     const char* kbuf = smem + BUF * KBYTES;
     const char* vbuf = smem + BUF * VBYTES;
     // -- online softmax, base 2
-    const float sc = __builtin_rintf(qsc * ksc[j * ksc_blk] * invg) * g;  // per-tile dequant scale on the g grid
-    const float c0 = -kMagic * sc;                              // exact
+    float sc, c0;
+    if constexpr (QK16) {
+      sc = p.qk_scale;  // fp32 scores: one fma per element, no bias to fold
+      c0 = 0.f;
+    } else {
+      sc = __builtin_rintf(qsc * ksc[j * ksc_blk] * invg) * g;  // per-tile dequant scale on the g grid
+      c0 = -kMagic * sc;                                        // exact
+    }
     float x[2][16];  // scores as floats kMagic + s (accumulator bits), then overwritten in place by P
     // -- S^T = K Q^T (int8 -> int32, biased by kMagic): two 32-key blocks
     auto compute_scores = [&]() {
@@ -265,15 +285,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
         i32x16 sacc;
+        f32x16 facc;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-          const i32x4 kf = *reinterpret_cast<const i32x4*>(kbuf + kf_base[s] + kb2 * 32 * D);
-          if (s == 0) sacc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], cmagic, 0, 0, 0);
-          else sacc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], sacc, 0, 0, 0);
+          const i32x4 kf = *reinterpret_cast<const i32x4*>(kbuf + kf_base[s] + kb2 * 32 * RB);
+          if constexpr (QK16) {
+            const f16x8 ka = __builtin_bit_cast(f16x8, kf), qb = __builtin_bit_cast(f16x8, qf[s]);
+            if (s == 0) facc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qb, f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+            else facc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qb, facc, 0, 0, 0);
+          } else {
+            if (s == 0) sacc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], cmagic, 0, 0, 0);
+            else sacc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], sacc, 0, 0, 0);
+          }
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          float tv = __int_as_float(sacc[i]);
+          float tv;
+          if constexpr (QK16) tv = facc[i];
+          else tv = __int_as_float(sacc[i]);
           if constexpr (MASKED) {
             const int key = j * 64 + 32 * kb2 + (i & 3) + 8 * (i >> 2) + 4 * hh;
             bool dead = key >= Sk;
@@ -299,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       const float xmax = __builtin_fmaf(tmax, sc, c0);  // row max of the dequantised scores; -inf if all masked
       // fp8 P: keep the exact row max as reference so that P_max = 448 = e4m3 max exactly, as the reference
       // specifies (attn_utils.cuh:30); c1 then carries a rounding of <= 2^-13 relative, invisible at 3 mantissa bits.
-      const float m_cand = fmaxf(m_run, FP8 ? xmax : grid_up(xmax));
+      const float m_cand = fmaxf(m_run, (FP8 || QK16) ? xmax : grid_up(xmax));
       if (__any(m_cand > m_run + thr)) {
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);  // m_run = -inf -> 0
         m_run = m_cand;
@@ -485,10 +514,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 hipError_t launch_attn_fwd(const AttnParams& p, int D, int v_dtype, int o_dtype, int causal, hipStream_t stream) {
   const unsigned n = (unsigned)p.B * p.Hq * p.nQ;
   dim3 grid(n), block(256);
-#define LBFA_A(DD, VT, OT)                                                                        \
-  do {                                                                                            \
-    if (causal) hipLaunchKernelGGL((attn_fwd_kernel<DD, VT, OT, true>), grid, block, 0, stream, p);  \
-    else hipLaunchKernelGGL((attn_fwd_kernel<DD, VT, OT, false>), grid, block, 0, stream, p);        \
+#define LBFA_A(DD, VT, OT)                                                                                 \
+  do {                                                                                                     \
+    if (causal) hipLaunchKernelGGL((attn_fwd_kernel<DD, kQInt8, VT, OT, true>), grid, block, 0, stream, p);  \
+    else hipLaunchKernelGGL((attn_fwd_kernel<DD, kQInt8, VT, OT, false>), grid, block, 0, stream, p);        \
   } while (0)
 #define LBFA_A2(DD, VT)                                   \
   do {                                                    \
@@ -506,6 +535,21 @@ hipError_t launch_attn_fwd(const AttnParams& p, int D, int v_dtype, int o_dtype,
 #undef LBFA_A3
 #undef LBFA_A2
 #undef LBFA_A
+  return hipGetLastError();
+}
+
+// un-quantised Q / K / V of one dtype (fp16, or bf16 converted to fp16 on the way into LDS / registers)
+hipError_t launch_attn_fwd_f16(const AttnParams& p, int D, int dtype, int causal, hipStream_t stream) {
+  const unsigned n = (unsigned)p.B * p.Hq * p.nQ;
+  dim3 grid(n), block(256);
+#define LBFA_F(DD, DT)                                                                                \
+  do {                                                                                                \
+    if (causal) hipLaunchKernelGGL((attn_fwd_kernel<DD, DT, DT, DT, true>), grid, block, 0, stream, p);  \
+    else hipLaunchKernelGGL((attn_fwd_kernel<DD, DT, DT, DT, false>), grid, block, 0, stream, p);        \
+  } while (0)
+  if (D == 64) { if (dtype == LBFA_F16) LBFA_F(64, LBFA_F16); else LBFA_F(64, LBFA_BF16); }
+  else { if (dtype == LBFA_F16) LBFA_F(128, LBFA_F16); else LBFA_F(128, LBFA_BF16); }
+#undef LBFA_F
   return hipGetLastError();
 }
 

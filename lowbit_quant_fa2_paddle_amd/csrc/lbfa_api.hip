@@ -16,6 +16,7 @@ hipError_t launch_quant_per_block(const QuantParams& p, int dtype, int D, int bl
 hipError_t launch_quant_v_fp8(const void* v, int dtype, uint8_t* out, float* v_scale, int B, int H, int S, int D,
                               int d_valid, const int64_t* st, hipStream_t stream);
 hipError_t launch_attn_fwd(const AttnParams& p, int D, int v_dtype, int o_dtype, int causal, hipStream_t stream);
+hipError_t launch_attn_fwd_f16(const AttnParams& p, int D, int dtype, int causal, hipStream_t stream);
 }  // namespace lbfa
 
 namespace {
@@ -43,6 +44,7 @@ void dense_scale_layout(lbfa::AttnParams& p) {
   p.qsc_b = (int64_t)p.Hq * p.nQ; p.qsc_h = p.nQ; p.qsc_blk = 1;
   p.ksc_b = (int64_t)p.Hkv * p.nK; p.ksc_h = p.nK; p.ksc_blk = 1;
   p.cu_q = p.cu_k = p.cu_qscale = p.cu_kscale = nullptr;
+  p.qk_scale = 0.f;
 }
 // head dims the one-call operators take directly: the kernels work on 64 / 128 channels and treat the rest as the
 // zero padding of src/core.py:277-287 (never read, never written)
@@ -392,6 +394,57 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
   return check_hip(launch_attention(p, D, v_dtype, dtype, is_causal ? 1 : 0, (hipStream_t)stream), "lbfa_forward launch");
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// un-quantised attention: the FP16 branch of the precision router (src/core.py:1066-1096 -> default_attn, :46-69)
+// ---------------------------------------------------------------------------------------------------------------
+int lbfa_sdpa_fwd(const void* q, const void* k, const void* v, int dtype, void* o, float* lse,
+                  int B, int Hq, int Hkv, int Sq, int Sk, int D,
+                  const int64_t strides_q[3], const int64_t strides_k[3], const int64_t strides_v[3],
+                  const int64_t strides_o[3], float sm_scale, int is_causal, void* stream) {
+  if (!q || !k || !v || !o || !strides_q || !strides_k || !strides_v || !strides_o) return fail(LBFA_EINVAL, "lbfa_sdpa_fwd: null pointer");
+  if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Sk <= 0) return fail(LBFA_EINVAL, "lbfa_sdpa_fwd: empty tensor");
+  if (!head_dim_ok(D)) return fail(LBFA_EINVAL, "Unsupported head_dim: %d", D);
+  if (Hq % Hkv != 0) return fail(LBFA_EINVAL, "num_qo_heads (%d) must be divisible by num_kv_heads (%d)", Hq, Hkv);
+  if (dtype != LBFA_F16 && dtype != LBFA_BF16) return fail(LBFA_EINVAL, "Input tensors must be in dtype of float16 or bfloat16");
+  if (is_causal && Sq != Sk) return fail(LBFA_EINVAL, "qo_len and kv_len must be equal for causal attention");
+  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (reinterpret_cast<uintptr_t>(o) & 7u))
+    return fail(LBFA_EINVAL, "lbfa_sdpa_fwd: q/k/v must be 16-byte aligned and o 8-byte aligned");
+  if ((strides_q[0] | strides_q[1] | strides_q[2] | strides_k[0] | strides_k[1] | strides_k[2] | strides_v[0] | strides_v[1] | strides_v[2]) % 8 != 0)
+    return fail(LBFA_EINVAL, "lbfa_sdpa_fwd: q/k/v strides must be multiples of 8 elements");
+  if ((strides_o[0] | strides_o[1] | strides_o[2]) % 4 != 0) return fail(LBFA_EINVAL, "lbfa_sdpa_fwd: o strides must be multiples of 4 elements");
+  {
+    const int64_t lim = 0x7fffffffLL;
+    if (2 * (((int64_t)Sq + LBFA_BLKQ) * strides_q[2] + D) > lim || 2 * (((int64_t)Sk + 2 * LBFA_BLKK) * strides_k[2] + D) > lim ||
+        2 * (((int64_t)Sk + 2 * LBFA_BLKK) * strides_v[2] + D) > lim)
+      return fail(LBFA_EINVAL, "lbfa_sdpa_fwd: per-(batch,head) operand window exceeds 2 GiB");
+  }
+  lbfa::AttnParams p;
+  p.q = (const int8_t*)q; p.k = (const int8_t*)k; p.v = v; p.o = o; p.lse = lse;
+  p.q_scale = nullptr; p.k_scale = nullptr; p.v_scale = nullptr;
+  p.qb = strides_q[0]; p.qh = strides_q[1]; p.qs = strides_q[2];
+  p.kb = strides_k[0]; p.kh = strides_k[1]; p.ks = strides_k[2];
+  p.vb = strides_v[0]; p.vh = strides_v[1]; p.vs = strides_v[2];
+  p.ob = strides_o[0]; p.oh = strides_o[1]; p.os = strides_o[2];
+  p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Sq = Sq; p.Sk = Sk;
+  p.nQ = (Sq + LBFA_BLKQ - 1) / LBFA_BLKQ;
+  p.nK = (Sk + LBFA_BLKK - 1) / LBFA_BLKK;
+  p.group = Hq / Hkv;
+  p.lse_corr = nullptr;
+  p.lse_scale = 1.0f / 1.44269504f;  // natural-log LSE
+  p.lse_corr_scale = 0.0f;
+  dense_scale_layout(p);
+  p.d_valid = D;
+  p.qk_scale = sm_scale * 1.44269504f;
+  if ((int64_t)B * Hq * p.nQ > 0x7fffffffLL) return fail(LBFA_EINVAL, "lbfa_sdpa_fwd: grid too large");
+  g_err[0] = 0;
+  const hipEvent_t e0 = g_prof_start, e1 = g_prof_stop;
+  g_prof_start = g_prof_stop = nullptr;
+  if (e0) (void)hipEventRecord(e0, (hipStream_t)stream);
+  const hipError_t err = lbfa::launch_attn_fwd_f16(p, padded_head_dim(D), dtype, is_causal ? 1 : 0, (hipStream_t)stream);
+  if (e1) (void)hipEventRecord(e1, (hipStream_t)stream);
+  return check_hip(err, "lbfa_sdpa_fwd launch");
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // packed variable-length batches (reference: sageattn_varlen, src/core.py:356-491)

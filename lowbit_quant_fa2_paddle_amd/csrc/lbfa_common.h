@@ -112,6 +112,7 @@ struct AttnParams {
   const int* cu_qscale;
   const int* cu_kscale;
   int d_valid;  // channels >= d_valid of V / O are padding: V reads as 0, O is not written (o has d_valid columns)
+  float qk_scale;  // un-quantised Q / K only: sm_scale * log2(e), applied to the fp32 scores
 };
 
 }  // namespace lbfa

@@ -22,6 +22,11 @@ CFG = {  # B,H,S,D,layout,causal,pv
     "c3": (4, 32, 16384, 128, "NHD", True, "fp16"),
     "c5": (2, 32, 32768, 128, "HND", False, "fp8"),
     "f8d64": (4, 32, 4096, 64, "HND", False, "fp8"),
+    # un-quantised kernel (lbfa_sdpa_fwd) and torch's flash SDPA on the same inputs
+    "h64": (4, 32, 4096, 64, "HND", False, "qk16"),
+    "h64c": (4, 32, 4096, 64, "HND", True, "qk16"),
+    "h128": (4, 32, 4096, 128, "HND", False, "qk16"),
+    "h128c": (4, 32, 16384, 128, "NHD", True, "qk16"),
 }
 
 
@@ -39,13 +44,20 @@ def main():
         q = torch.randn(shp, generator=g, device=dev).half()
         k = torch.randn(shp, generator=g, device=dev).half()
         v = torch.randn(shp, generator=g, device=dev).half()
-        km = qpb.mean_seq(k, layout)
-        q8, qs, k8, ks = qpb.per_block_int8(q, k, km=km, sm_scale=D ** -0.5, tensor_layout=layout)
-        if pv == "fp8":
+        if pv == "qk16":
+            from lowbit_quant_fa2_paddle_amd import core
+            f = lambda: (core.flash_attn_fp16(q, k, v, tensor_layout=layout, is_causal=causal), None)
+        else:
+            km = qpb.mean_seq(k, layout)
+            q8, qs, k8, ks = qpb.per_block_int8(q, k, km=km, sm_scale=D ** -0.5, tensor_layout=layout)
+        if pv == "qk16":
+            pass
+        elif pv == "fp8":
             vin, vs, _ = quant.per_channel_fp8(v, tensor_layout=layout)
         else:
             vin, vs = v, None
-        f = lambda: attn.forward(q8, k8, vin, qs, ks, tensor_layout=layout, output_dtype=torch.float16, is_causal=causal, v_scale=vs)
+        if pv != "qk16":
+            f = lambda: attn.forward(q8, k8, vin, qs, ks, tensor_layout=layout, output_dtype=torch.float16, is_causal=causal, v_scale=vs)
         for _ in range(3):
             o, _ = f()
         torch.cuda.synchronize()
@@ -66,6 +78,18 @@ def main():
             oo = (o if layout == "HND" else o.transpose(1, 2))[0, :hb].float()
             ref = torch.nn.functional.scaled_dot_product_attention(qq[None], kk[None], vv[None], is_causal=causal)[0]
             msg += f"  mse {float(((oo - ref) ** 2).mean()):.2e} maxabs {float((oo - ref).abs().max()):.2e}"
+        if pv == "qk16":  # FA2-class library kernel on the same inputs
+            from torch.nn.attention import SDPBackend, sdpa_kernel
+            qq, kk, vv = ((x if layout == "HND" else x.transpose(1, 2)) for x in (q, k, v))
+            with sdpa_kernel(SDPBackend.FLASH_ATTENTION):
+                for _ in range(3):
+                    torch.nn.functional.scaled_dot_product_attention(qq, kk, vv, is_causal=causal)
+                t2 = []
+                for _ in range(a.iters):
+                    e0.record(); torch.nn.functional.scaled_dot_product_attention(qq, kk, vv, is_causal=causal); e1.record()
+                    torch.cuda.synchronize(); t2.append(e0.elapsed_time(e1))
+            t2.sort()
+            msg += f"  | torch flash {fl / t2[len(t2) // 2] / 1e9:8.1f} TFLOP/s"
         print(msg, flush=True)
 
 

@@ -160,31 +160,40 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   if constexpr (CAUSAL) n_tiles = min(nK, 2 * (qt + 1));
 
   // ---- loop-invariant per-thread offsets: global (voffset) and LDS -----------------------------------
-  unsigned k_goff[KCH], k_loff[KCH], v_goff[VCH], v_loff[VCH];
-#pragma unroll
-  for (int i = 0; i < KCH; ++i) {
-    const int c = t + 256 * i, row = c / (RB / 16), ch = c % (RB / 16);
-    k_goff[i] = ch * 16 < ESZ * dq_valid ? ESZ * (unsigned)row * (unsigned)p.ks + ch * 16 : 0x80000000u;
-    k_loff[i] = row * RB + ((ch ^ kx<RB>(row)) << 4);
+  // Chunk i of a thread is chunk 0 moved down by a whole number of rows (KROWS / VROWS per pass), which leaves the
+  // swizzles unchanged: one voffset / LDS offset per operand, the rest is a scalar soffset and a ds immediate.
+  constexpr int KCPR = RB / 16, KROWS = 256 / KCPR;              // K: 16-B chunks per row, rows per pass
+  constexpr int VCPR = FP8 ? 1 : D / 8, VROWS = FP8 ? 0 : 256 / VCPR;
+  unsigned k_goff, k_loff, v_goff, v_loff;
+  {
+    const int row = t / KCPR, ch = t % KCPR;
+    // padded channels: an offset beyond any window -> the range check returns zeros (windows are < 2 GiB, checked by the C ABI)
+    k_goff = ch * 16 < ESZ * dq_valid ? ESZ * (unsigned)row * (unsigned)p.ks + ch * 16 : 0x80000000u;
+    k_loff = row * RB + ((ch ^ kx<RB>(row)) << 4);
   }
-#pragma unroll
-  for (int i = 0; i < VCH; ++i) {
-    if constexpr (FP8) {
-      v_goff[i] = (t + 256 * i) * 16;
-      v_loff[i] = 2 * KBYTES + (t + 256 * i) * 16;
-    } else {
-      const int c = t + 256 * i, row = c / (D / 8), ch = c % (D / 8);
-      // padded channels: an offset beyond any window -> the range check returns zeros
-      v_goff[i] = ch * 8 < p.d_valid ? 2 * ((unsigned)row * (unsigned)p.vs) + ch * 16 : 0x80000000u;  // windows are < 2 GiB (checked by the C ABI)
-      v_loff[i] = 2 * KBYTES + row * (2 * D) + (((ch >> 2) ^ vx<D>(row)) << 6) + ((ch & 3) << 4);
-    }
+  if constexpr (FP8) {
+    v_goff = t * 16;
+    v_loff = 2 * KBYTES + t * 16;
+  } else {
+    const int row = t / VCPR, ch = t % VCPR;
+    v_goff = ch * 8 < p.d_valid ? 2 * ((unsigned)row * (unsigned)p.vs) + ch * 16 : 0x80000000u;
+    v_loff = 2 * KBYTES + row * (2 * D) + (((ch >> 2) ^ vx<D>(row)) << 6) + ((ch & 3) << 4);
   }
+  const unsigned k_gstep = ESZ * KROWS * (unsigned)p.ks;                  // bytes between a thread's K chunks
+  const unsigned v_gstep = FP8 ? 4096u : 2u * VROWS * (unsigned)p.vs;
+  constexpr int K_LSTEP = KROWS * RB, V_LSTEP = FP8 ? 4096 : VROWS * 2 * D;
   // Fragment read addresses.  The swizzles depend only on the low row bits, so the block / k-step / high-half /
   // buffer parts are compile-time byte offsets folded into the ds_read immediates; per lane only KS (K) and
   // DB or 4 (V) base registers are needed.
-  unsigned kf_base[KS];  // + kb2 * 32 * RB
+  // K: chunk (2s + hh) ^ kx(r) of row r.  r * RB has no bits below RB, so the address is kf_lane ^ (s << 5) with
+  // kf_lane = r * RB + ((hh ^ kx(r)) << 4): with many k-steps (fp16, D = 128) one v_xor per fragment replaces KS registers.
+  constexpr bool KF_XOR = (KS >= 8);
+  const unsigned kf_lane = r * RB + ((hh ^ kx<RB>(r)) << 4);
+  unsigned kf_base[KF_XOR ? 1 : KS];  // + kb2 * 32 * RB
+  if constexpr (!KF_XOR) {
 #pragma unroll
-  for (int s = 0; s < KS; ++s) kf_base[s] = r * RB + (((2 * s + hh) ^ kx<RB>(r)) << 4);
+    for (int s = 0; s < KS; ++s) kf_base[s] = kf_lane ^ (s << 5);
+  }
   constexpr int NVB = FP8 ? 4 : DB;
   unsigned vf_base[NVB];  // f16: [db] + ks*16*2D + hi*8*2D ;  fp8: [ks] + db*32*64
 #pragma unroll
@@ -205,9 +214,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     const __amdgpu_buffer_rsrc_t k_rs = make_rsrc(kbase + ko, (unsigned)max((int64_t)0, k_bytes - ko));
     const __amdgpu_buffer_rsrc_t v_rs = make_rsrc(vbase + vo, (unsigned)max((int64_t)0, v_bytes - vo));
 #pragma unroll
-    for (int i = 0; i < KCH; ++i) kreg[i] = buf_load16(k_rs, k_goff[i], 0);
+    for (int i = 0; i < KCH; ++i) kreg[i] = buf_load16(k_rs, k_goff, i * k_gstep);
 #pragma unroll
-    for (int i = 0; i < VCH; ++i) vreg[i] = buf_load16(v_rs, v_goff[i], 0);
+    for (int i = 0; i < VCH; ++i) vreg[i] = buf_load16(v_rs, v_goff, i * v_gstep);
   };
   auto store_tile = [&](auto buf_tag) {
     constexpr int BUF = decltype(buf_tag)::value;
@@ -215,13 +224,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     for (int i = 0; i < KCH; ++i) {
       u32x4 val = kreg[i];
       if constexpr (QT == LBFA_BF16) val = bf16x8_to_f16x8(val);
-      *reinterpret_cast<u32x4*>(smem + k_loff[i] + BUF * KBYTES) = val;
+      *reinterpret_cast<u32x4*>(smem + k_loff + i * K_LSTEP + BUF * KBYTES) = val;
     }
 #pragma unroll
     for (int i = 0; i < VCH; ++i) {
       u32x4 val = vreg[i];
       if constexpr (VT == LBFA_BF16) val = bf16x8_to_f16x8(val);  // bf16 -> fp16 on the way in (src/core.py:307-308 `v.to(float16)`)
-      *reinterpret_cast<u32x4*>(smem + v_loff[i] + BUF * VBYTES) = val;
+      *reinterpret_cast<u32x4*>(smem + v_loff + i * V_LSTEP + BUF * VBYTES) = val;
     }
   };
 
@@ -288,7 +297,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         f32x16 facc;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-          const i32x4 kf = *reinterpret_cast<const i32x4*>(kbuf + kf_base[s] + kb2 * 32 * RB);
+          const unsigned kfa = KF_XOR ? (kf_lane ^ (unsigned)(s << 5)) : kf_base[KF_XOR ? 0 : s];
+          const i32x4 kf = *reinterpret_cast<const i32x4*>(kbuf + kfa + kb2 * 32 * RB);
           if constexpr (QK16) {
             const f16x8 ka = __builtin_bit_cast(f16x8, kf), qb = __builtin_bit_cast(f16x8, qf[s]);
             if (s == 0) facc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qb, f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);

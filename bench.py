@@ -133,12 +133,13 @@ def main():
     # (lbfa_profile_next_attn: the next fused-attention launch is bracketed by the two events), inside the timed region
     lib = _lib.load()
     attn_events = []
-
-    def arm_kernel_timer():
+    for _ in range(args.steps):  # created and materialised before the timed region (the library re-records them)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); e1.record()  # materialise the hipEvent handles (re-recorded by the library)
-        lib.lbfa_profile_next_attn(e0.cuda_event, e1.cuda_event)
-        attn_events.append((e0, e1))
+        e0.record(); e1.record()
+        attn_events.append((e0, e1, e0.cuda_event, e1.cuda_event))
+
+    def arm_kernel_timer(i):
+        lib.lbfa_profile_next_attn(attn_events[i][2], attn_events[i][3])
 
     def barrier():
         if distributed:
@@ -149,8 +150,8 @@ def main():
         o = step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        arm_kernel_timer()
+    for i in range(args.steps):
+        arm_kernel_timer(i)
         o = step()
     barrier()
     t1 = time.perf_counter()
@@ -163,7 +164,7 @@ def main():
     flops_rank = 4.0 * B * H * D * S * S / (2 if causal else 1)
     value = world * flops_rank / (elapsed / args.steps) / 1e12
 
-    kern_ms = sum(a.elapsed_time(b) for a, b in attn_events) / max(len(attn_events), 1)
+    kern_ms = sum(ev[0].elapsed_time(ev[1]) for ev in attn_events) / max(len(attn_events), 1)
     achieved = flops_rank / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
     peak = PEAK_MIX_TF
     traffic = None
@@ -206,6 +207,19 @@ def main():
                    "speedup_kernel_only": round(achieved / (flops_rank / dt / 1e12), 3) if achieved else None}
         except Exception as e:  # backend not available for this shape/build
             fa2 = {"impl": "torch SDPA flash backend", "error": str(e)[:120]}
+        # ... and this library's own un-quantised kernel (lbfa_sdpa_fwd: same tiling, fp16 MFMAs for both products)
+        from lowbit_quant_fa2_paddle_amd import core as _core
+        for _ in range(3):
+            _core.flash_attn_fp16(q, k, v, tensor_layout=layout, is_causal=causal)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            _core.flash_attn_fp16(q, k, v, tensor_layout=layout, is_causal=causal)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        fa2["own_fp16_kernel"] = {"impl": "lbfa_sdpa_fwd (this library, un-quantised fp16 QK^T and PV), same inputs",
+                                  "tflops": round(flops_rank / dt / 1e12, 2), "ms": round(dt * 1e3, 4),
+                                  "lowbit_speedup_whole_op": round(dt / (elapsed / args.steps), 3)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -60,8 +60,9 @@ __device__ __forceinline__ float ones_rowsum(const PF (&pf)[4]) {
   }
 }
 
-template <int D, int QT, int VT, int OT, bool CAUSAL>
+template <int D, int QT, int VT, int OT, bool CAUSAL, bool QQ = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+  static_assert(!QQ || QT == kQInt8, "in-kernel Q quantisation belongs to the int8 path");
   constexpr bool FP8 = (VT == LBFA_E4M3);
   // QT = kQInt8: the low-bit path.  QT = LBFA_F16 / LBFA_BF16: un-quantised Q and K (the FP16 branch of the
   // precision router, src/core.py:1066-1096): same tiling and softmax, scores from v_mfma_f32_32x32x16_f16 on fp16
@@ -121,7 +122,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   // ---- operand windows (bytes).  The descriptor is re-based per tile with scalar arithmetic, so the
   // hardware range check sees only the loop-invariant per-lane offset.
   const int dq_valid = QK16 ? p.d_valid : D;  // un-quantised Q / K come from the caller's tensors: head-dim padding applies
-  const char* qbase = (const char*)p.q + ESZ * (q_off + (int64_t)h * p.qh);
   const char* kbase = (const char*)p.k + ESZ * (k_off + (int64_t)hk * p.kh);
   const int64_t k_bytes = ESZ * ((int64_t)(Sk - 1) * p.ks + dq_valid);
   const int64_t k_tile_stride = ESZ * 64 * p.ks;
@@ -136,24 +136,88 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     v_bytes = 2 * ((int64_t)(Sk - 1) * p.vs + p.d_valid);
     v_tile_stride = 128 * p.vs;
   }
-  const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(qbase, (unsigned)(ESZ * ((int64_t)(Sq - 1) * p.qs + dq_valid)));
 
   // ---- Q fragments (B operand of the score MFMA): lane (r, hh) holds bytes [32s+16hh, +16) of its row.
   // Rows >= Sq are out of the descriptor's range and read as zeros.
   i32x4 qf[KS];
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const unsigned col_b = 16 * hh + 32 * s;  // byte column
-    u32x4 raw = buf_load16(q_rs, col_b < (unsigned)(ESZ * dq_valid) ? ESZ * (unsigned)qrow * (unsigned)p.qs + col_b : 0x80000000u, 0);
-    if constexpr (QT == LBFA_BF16) raw = bf16x8_to_f16x8(raw);
-    qf[s] = __builtin_bit_cast(i32x4, raw);
-  }
   float qsc = 1.0f;
-  const float* ksc = nullptr;
-  if constexpr (!QK16) {
-    qsc = p.q_scale[qsc_base + (int64_t)h * p.qsc_h + (int64_t)qt * p.qsc_blk];
-    ksc = p.k_scale + ksc_base + (int64_t)hk * p.ksc_h;
+  float row_corr = 0.f;  // QQ: lse correction q . km of this lane's row
+  if constexpr (QQ) {
+    // Quantise this workgroup's 128 x D block of Q here instead of in a pre-pass (src/triton/quant_per_block.py:132-178,
+    // same arithmetic as quant_per_block_kernel: x * sm_scale -> block amax -> scale = amax / qmax -> RN(x / scale) ->
+    // round half away): the lane needs exactly the 16 * KS elements it feeds to the MFMA.
+    const char* qsrc = (const char*)p.q + 2 * (q_off + (int64_t)h * p.qh);
+    const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(qsrc, (unsigned)(2 * ((int64_t)(Sq - 1) * p.qs + p.d_valid)));
+    float xs[KS][16];
+    float amax = 0.f, dot = 0.f;
+    const unsigned short* vec = p.q_dot_vec ? p.q_dot_vec + ((int64_t)b * p.Hkv + hk) * D : nullptr;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int col = 32 * s + 16 * hh + 8 * hf;
+        const u32x4 raw = buf_load16(q_rs, col < p.d_valid ? 2 * ((unsigned)qrow * (unsigned)p.qs + col) : 0x80000000u, 0);
+        u32x4 vraw = u32x4{0, 0, 0, 0};
+        if (vec != nullptr) vraw = *reinterpret_cast<const u32x4*>(vec + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xv = load_cvt<OT>((unsigned short)((e & 1) ? (raw[e >> 1] >> 16) : (raw[e >> 1] & 0xffffu)));
+          const float kv = load_cvt<OT>((unsigned short)((e & 1) ? (vraw[e >> 1] >> 16) : (vraw[e >> 1] & 0xffffu)));
+          dot += xv * kv;
+          const float x = xv * p.q_sm_scale;
+          xs[s][8 * hf + e] = x;
+          amax = fmaxf(amax, fabsf(x));
+        }
+      }
+    row_corr = load_cvt<OT>(store_cvt<OT>(half_swap_sum(dot)));  // rounded to the storage dtype (src/core.py:294-304)
+    amax = wave_max(amax);
+    float* red = reinterpret_cast<float*>(smem);
+    if (lane == 0) red[wave] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();  // smem is about to be overwritten by the first K / V tile
+    const float scale = fmaxf(amax, 1e-7f) / p.q_qmax;
+    qsc = scale;
+    const float rcp = 1.0f / scale;
+    const bool exact_rcp_ok = (__builtin_amdgcn_readfirstlane(__float_as_uint(scale)) & 0x7fffffu) != 0x7fffffu;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      unsigned w[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        int qv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xv = xs[s][4 * g4 + e];
+          float y;
+          if (exact_rcp_ok) {  // Markstein: RN(x / scale) from the correctly rounded reciprocal (see quant_kernels.hip)
+            const float q0 = xv * rcp;
+            y = __builtin_fmaf(__builtin_fmaf(-q0, scale, xv), rcp, q0);
+          } else {
+            y = xv / scale;
+          }
+          qv[e] = (int)(y + __builtin_copysignf(0.5f, y));
+        }
+        const unsigned p01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(qv[0], qv[1]));
+        const unsigned p23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(qv[2], qv[3]));
+        w[g4] = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
+      }
+      qf[s] = i32x4{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+    }
+  } else {
+    const char* qbase = (const char*)p.q + ESZ * (q_off + (int64_t)h * p.qh);
+    const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(qbase, (unsigned)(ESZ * ((int64_t)(Sq - 1) * p.qs + dq_valid)));
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const unsigned col_b = 16 * hh + 32 * s;  // byte column
+      u32x4 raw = buf_load16(q_rs, col_b < (unsigned)(ESZ * dq_valid) ? ESZ * (unsigned)qrow * (unsigned)p.qs + col_b : 0x80000000u, 0);
+      if constexpr (QT == LBFA_BF16) raw = bf16x8_to_f16x8(raw);
+      qf[s] = __builtin_bit_cast(i32x4, raw);
+    }
+    if constexpr (!QK16) qsc = p.q_scale[qsc_base + (int64_t)h * p.qsc_h + (int64_t)qt * p.qsc_blk];
   }
+  const float* ksc = nullptr;
+  if constexpr (!QK16) ksc = p.k_scale + ksc_base + (int64_t)hk * p.ksc_h;
   const int ksc_blk = (int)p.ksc_blk;
 
   int n_tiles = nK;
@@ -515,7 +579,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       if constexpr (FP8) ls -= kFp8Offset;  // qk_int_sv_f8_cuda.cu:689
       const int64_t li = ((int64_t)b * p.Hq + h) * p.Sq + qrow;  // dense only (the packed entry points take no lse)
       ls *= p.lse_scale;
-      if (p.lse_corr != nullptr) ls += p.lse_corr[li] * p.lse_corr_scale;
+      if constexpr (QQ) ls += row_corr * p.lse_corr_scale;  // 0 when there is no smoothing vector
+      else if (p.lse_corr != nullptr) ls += p.lse_corr[li] * p.lse_corr_scale;
       p.lse[li] = ls;
     }
   }
@@ -545,6 +610,32 @@ hipError_t launch_attn_fwd(const AttnParams& p, int D, int v_dtype, int o_dtype,
 #undef LBFA_A3
 #undef LBFA_A2
 #undef LBFA_A
+  return hipGetLastError();
+}
+
+// int8 K codes, Q quantised inside the kernel from its fp16 / bf16 source (dtype = Q's = O's); V of the same dtype or e4m3
+hipError_t launch_attn_fwd_qq(const AttnParams& p, int D, int dtype, int v_fp8, int causal, hipStream_t stream) {
+  const unsigned n = (unsigned)p.B * p.Hq * p.nQ;
+  dim3 grid(n), block(256);
+#define LBFA_QQ(DD, VT, DT)                                                                                       \
+  do {                                                                                                            \
+    if (causal) hipLaunchKernelGGL((attn_fwd_kernel<DD, kQInt8, VT, DT, true, true>), grid, block, 0, stream, p);   \
+    else hipLaunchKernelGGL((attn_fwd_kernel<DD, kQInt8, VT, DT, false, true>), grid, block, 0, stream, p);         \
+  } while (0)
+#define LBFA_QQ2(DD)                                                     \
+  do {                                                                   \
+    if (dtype == LBFA_F16) {                                             \
+      if (v_fp8) LBFA_QQ(DD, LBFA_E4M3, LBFA_F16);                       \
+      else LBFA_QQ(DD, LBFA_F16, LBFA_F16);                              \
+    } else {                                                             \
+      if (v_fp8) LBFA_QQ(DD, LBFA_E4M3, LBFA_BF16);                      \
+      else LBFA_QQ(DD, LBFA_BF16, LBFA_BF16);                            \
+    }                                                                    \
+  } while (0)
+  if (D == 64) LBFA_QQ2(64);
+  else LBFA_QQ2(128);
+#undef LBFA_QQ2
+#undef LBFA_QQ
   return hipGetLastError();
 }
 

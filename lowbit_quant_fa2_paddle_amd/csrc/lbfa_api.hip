@@ -17,6 +17,7 @@ hipError_t launch_quant_v_fp8(const void* v, int dtype, uint8_t* out, float* v_s
                               int d_valid, const int64_t* st, hipStream_t stream);
 hipError_t launch_attn_fwd(const AttnParams& p, int D, int v_dtype, int o_dtype, int causal, hipStream_t stream);
 hipError_t launch_attn_fwd_f16(const AttnParams& p, int D, int dtype, int causal, hipStream_t stream);
+hipError_t launch_attn_fwd_qq(const AttnParams& p, int D, int dtype, int v_fp8, int causal, hipStream_t stream);
 }  // namespace lbfa
 
 namespace {
@@ -24,7 +25,8 @@ thread_local char g_err[512] = "";
 thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;  // one-shot, see lbfa_profile_next_attn
 
 // launches the fused attention kernel, bracketed by the caller's events when a profile request is pending
-hipError_t launch_attention(const lbfa::AttnParams& p, int D, int v_dtype, int o_dtype, int causal, hipStream_t stream);
+hipError_t launch_attention(const lbfa::AttnParams& p, int D, int v_dtype, int o_dtype, int causal, hipStream_t stream,
+                            bool quantise_q = false);
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -45,6 +47,7 @@ void dense_scale_layout(lbfa::AttnParams& p) {
   p.ksc_b = (int64_t)p.Hkv * p.nK; p.ksc_h = p.nK; p.ksc_blk = 1;
   p.cu_q = p.cu_k = p.cu_qscale = p.cu_kscale = nullptr;
   p.qk_scale = 0.f;
+  p.q_sm_scale = 0.f; p.q_qmax = 127.f; p.q_dot_vec = nullptr;
 }
 // head dims the one-call operators take directly: the kernels work on 64 / 128 channels and treat the rest as the
 // zero padding of src/core.py:277-287 (never read, never written)
@@ -53,11 +56,13 @@ int padded_head_dim(int D) { return D <= 64 ? 64 : 128; }
 }  // namespace
 
 namespace {
-hipError_t launch_attention(const lbfa::AttnParams& p, int D, int v_dtype, int o_dtype, int causal, hipStream_t stream) {
+hipError_t launch_attention(const lbfa::AttnParams& p, int D, int v_dtype, int o_dtype, int causal, hipStream_t stream,
+                            bool quantise_q) {
   const hipEvent_t e0 = g_prof_start, e1 = g_prof_stop;
   g_prof_start = g_prof_stop = nullptr;
   if (e0) (void)hipEventRecord(e0, stream);
-  const hipError_t err = lbfa::launch_attn_fwd(p, D, v_dtype, o_dtype, causal, stream);
+  const hipError_t err = quantise_q ? lbfa::launch_attn_fwd_qq(p, D, o_dtype, v_dtype == LBFA_E4M3, causal, stream)
+                                    : lbfa::launch_attn_fwd(p, D, v_dtype, o_dtype, causal, stream);
   if (e1) (void)hipEventRecord(e1, stream);
   return err;
 }
@@ -297,11 +302,11 @@ FwdLayout fwd_layout(int B, int Hq, int Hkv, int Sq, int Sk, int D, int pv_fp8, 
   auto take = [&](size_t n) { size_t at = o; o += align256(n); return at; };
   L.km = take((size_t)B * Hkv * D * 2);
   L.part = take(lbfa_mean_seq_workspace_bytes(B, Hkv, Sk, D));
-  L.q8 = take((size_t)B * Hq * Sq * D);
+  // Q is quantised inside the attention kernel (no codes, scales or lse-correction buffers)
+  (void)Hq; (void)Sq; (void)want_corr;
+  L.q8 = L.qs = L.corr = 0;
   L.k8 = take((size_t)B * Hkv * Sk * D);
-  L.qs = take((size_t)B * Hq * ((Sq + LBFA_BLKQ - 1) / LBFA_BLKQ) * 4);
   L.ks = take((size_t)B * Hkv * ((Sk + LBFA_BLKK - 1) / LBFA_BLKK) * 4);
-  L.corr = take(want_corr ? (size_t)B * Hq * Sq * 4 : 0);
   L.v8 = take(pv_fp8 ? lbfa_v_fp8_bytes(B, Hkv, Sk, D) : 0);
   L.vs = take(pv_fp8 ? (size_t)B * Hkv * D * 4 : 0);
   L.total = o;
@@ -332,22 +337,19 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
   if (!aligned16(workspace)) return fail(LBFA_EINVAL, "lbfa_forward: workspace must be 16-byte aligned");
   char* ws = (char*)workspace;
   void* km = smooth_k ? (void*)(ws + L.km) : nullptr;
-  int8_t* q8 = (int8_t*)(ws + L.q8);
   int8_t* k8 = (int8_t*)(ws + L.k8);
-  float* qs = (float*)(ws + L.qs);
   float* ks = (float*)(ws + L.ks);
-  float* corr = want_corr ? (float*)(ws + L.corr) : nullptr;
-  const int64_t sq8[3] = {(int64_t)Hq * Sq * D, (int64_t)Sq * D, D};     // int8 codes: contiguous [B,H,S,D]
   const int64_t sk8[3] = {(int64_t)Hkv * Sk * D, (int64_t)Sk * D, D};
   int st;
   if (smooth_k) {
     st = mean_impl(k, dtype, km, ws + L.part, lbfa_mean_seq_workspace_bytes(B, Hkv, Sk, D), B, Hkv, Sk, D, Dg, strides_k, stream);
     if (st) return st;
   }
-  // Q: sm_scale * log2(e) folded into the codes' scale (src/triton/quant_per_block.py:226); lse_correction = q . km
-  st = quant_impl(q, dtype, nullptr, 1, q8, qs, sm_scale * 1.44269504f, q_qmax, LBFA_BLKQ, B, Hq, Sq, D, Dg, strides_q, sq8,
-                  want_corr ? km : nullptr, Hq / Hkv, corr, stream);
-  if (st) return st;
+  // Q is quantised by the attention kernel itself (each workgroup its own 128-row block: same codes and scales as
+  // lbfa_quant_per_block, sm_scale * log2(e) folded in, src/triton/quant_per_block.py:226), as is lse_correction = q . km
+  if (q_qmax != 127 && q_qmax != 7) return fail(LBFA_EINVAL, "lbfa_forward: q_qmax must be 127 (int8) or 7 (int4 range), got %d", q_qmax);
+  if (!aligned16(q) || (strides_q[0] | strides_q[1] | strides_q[2]) % 8 != 0)
+    return fail(LBFA_EINVAL, "lbfa_forward: q must be 16-byte aligned with strides that are multiples of 8 elements");
   st = quant_impl(k, dtype, km, 1, k8, ks, 1.0f, k_qmax, LBFA_BLKK, B, Hkv, Sk, D, Dg, strides_k, sk8, nullptr, 1, nullptr, stream);
   if (st) return st;
   const void* v_in = v;
@@ -369,13 +371,13 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
   {
     const int64_t lim = 0x7fffffffLL;
     const int64_t vwin = v_dtype == LBFA_E4M3 ? ((int64_t)Sk + 2 * LBFA_BLKK) * D : 2 * (((int64_t)Sk + 2 * LBFA_BLKK) * strides_v[2] + D);
-    if (((int64_t)Sq + LBFA_BLKQ) * D + D > lim || ((int64_t)Sk + 2 * LBFA_BLKK) * D + D > lim || vwin > lim)
+    if (2 * (((int64_t)Sq + LBFA_BLKQ) * strides_q[2] + D) > lim || ((int64_t)Sk + 2 * LBFA_BLKK) * D + D > lim || vwin > lim)
       return fail(LBFA_EINVAL, "lbfa_forward: per-(batch,head) operand window exceeds 2 GiB");
   }
   lbfa::AttnParams p;
-  p.q = q8; p.k = k8; p.v = v_in; p.o = o; p.lse = lse;
-  p.q_scale = qs; p.k_scale = ks; p.v_scale = v_scale;
-  p.qb = sq8[0]; p.qh = sq8[1]; p.qs = sq8[2];
+  p.q = (const int8_t*)q; p.k = k8; p.v = v_in; p.o = o; p.lse = lse;
+  p.q_scale = nullptr; p.k_scale = ks; p.v_scale = v_scale;
+  p.qb = strides_q[0]; p.qh = strides_q[1]; p.qs = strides_q[2];
   p.kb = sk8[0]; p.kh = sk8[1]; p.ks = sk8[2];
   if (v_dtype != LBFA_E4M3) { p.vb = strides_v[0]; p.vh = strides_v[1]; p.vs = strides_v[2]; }
   else { p.vb = p.vh = p.vs = 0; }
@@ -384,14 +386,17 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
   p.nQ = (Sq + LBFA_BLKQ - 1) / LBFA_BLKQ;
   p.nK = (Sk + LBFA_BLKK - 1) / LBFA_BLKK;
   p.group = Hq / Hkv;
-  p.lse_corr = corr;
+  p.lse_corr = nullptr;
   p.lse_scale = 1.0f / 1.44269504f;   // natural-log LSE (src/core.py:347)
   p.lse_corr_scale = sm_scale;
   dense_scale_layout(p);
   p.d_valid = Dg;
+  p.q_sm_scale = sm_scale * 1.44269504f;
+  p.q_qmax = (float)q_qmax;
+  p.q_dot_vec = want_corr ? (const unsigned short*)km : nullptr;
   if ((int64_t)B * Hq * p.nQ > 0x7fffffffLL) return fail(LBFA_EINVAL, "lbfa_forward: grid too large");
   g_err[0] = 0;
-  return check_hip(launch_attention(p, D, v_dtype, dtype, is_causal ? 1 : 0, (hipStream_t)stream), "lbfa_forward launch");
+  return check_hip(launch_attention(p, D, v_dtype, dtype, is_causal ? 1 : 0, (hipStream_t)stream, true), "lbfa_forward launch");
 }
 
 
@@ -454,8 +459,8 @@ int attn_varlen_core(const char* who, const int8_t* q, const int8_t* k, const vo
                      const float* q_scale, const float* k_scale, const int32_t* cu_q, const int32_t* cu_k,
                      const int32_t* cu_qscale, const int32_t* cu_kscale, int B, int Hq, int Hkv, int max_q, int max_k, int D,
                      int d_valid, const int64_t sq[2], const int64_t sk[2], const int64_t sv[2], const int64_t so[2], int is_causal,
-                     void* stream) {
-  if (!q || !k || !v || !o || !q_scale || !k_scale || !cu_q || !cu_k || !sq || !sk || !sv || !so)
+                     void* stream, bool quantise_q = false, float q_sm_scale = 0.f, int q_qmax = 127) {
+  if (!q || !k || !v || !o || (!q_scale && !quantise_q) || !k_scale || !cu_q || !cu_k || !sq || !sk || !sv || !so)
     return fail(LBFA_EINVAL, "%s: null pointer", who);
   if ((cu_qscale == nullptr) != (cu_kscale == nullptr)) return fail(LBFA_EINVAL, "%s: give both scale offset tables or neither", who);
   if (B <= 0 || Hq <= 0 || Hkv <= 0 || max_q <= 0 || max_k <= 0) return fail(LBFA_EINVAL, "%s: empty batch", who);
@@ -465,12 +470,14 @@ int attn_varlen_core(const char* who, const int8_t* q, const int8_t* k, const vo
   if (o_dtype != LBFA_F16 && o_dtype != LBFA_BF16) return fail(LBFA_EINVAL, "%s: bad o_dtype %d", who, o_dtype);
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (reinterpret_cast<uintptr_t>(o) & 7u))
     return fail(LBFA_EINVAL, "%s: q/k/v must be 16-byte aligned and o 8-byte aligned", who);
-  if ((sq[0] | sq[1] | sk[0] | sk[1]) % 16 != 0) return fail(LBFA_EINVAL, "%s: q/k strides must be multiples of 16 elements", who);
+  if (((quantise_q ? 0 : (sq[0] | sq[1])) | sk[0] | sk[1]) % 16 != 0) return fail(LBFA_EINVAL, "%s: q/k strides must be multiples of 16 elements", who);
+  if (quantise_q && (sq[0] | sq[1]) % 8 != 0) return fail(LBFA_EINVAL, "%s: q strides must be multiples of 8 elements", who);
+  if (quantise_q && q_qmax != 127 && q_qmax != 7) return fail(LBFA_EINVAL, "%s: q_qmax must be 127 (int8) or 7 (int4 range), got %d", who, q_qmax);
   if ((sv[0] | sv[1]) % 8 != 0) return fail(LBFA_EINVAL, "%s: v strides must be multiples of 8 elements", who);
   if ((so[0] | so[1]) % 4 != 0) return fail(LBFA_EINVAL, "%s: o strides must be multiples of 4 elements", who);
   {
     const int64_t lim = 0x7fffffffLL;
-    if (((int64_t)max_q + LBFA_BLKQ) * sq[1] + D > lim || ((int64_t)max_k + 2 * LBFA_BLKK) * sk[1] + D > lim ||
+    if ((quantise_q ? 2 : 1) * (((int64_t)max_q + LBFA_BLKQ) * sq[1] + D) > lim || ((int64_t)max_k + 2 * LBFA_BLKK) * sk[1] + D > lim ||
         2 * (((int64_t)max_k + 2 * LBFA_BLKK) * sv[1] + D) > lim)
       return fail(LBFA_EINVAL, "%s: per-sequence operand window exceeds 2 GiB (token stride x max_seqlen too large)", who);
   }
@@ -493,9 +500,10 @@ int attn_varlen_core(const char* who, const int8_t* q, const int8_t* k, const vo
   }
   p.cu_q = cu_q; p.cu_k = cu_k; p.cu_qscale = cu_qscale; p.cu_kscale = cu_kscale;
   p.d_valid = d_valid;
+  p.q_sm_scale = q_sm_scale; p.q_qmax = (float)q_qmax;
   if ((int64_t)B * Hq * p.nQ > 0x7fffffffLL) return fail(LBFA_EINVAL, "%s: grid too large", who);
   g_err[0] = 0;
-  return check_hip(launch_attention(p, D, v_dtype, o_dtype, is_causal ? 1 : 0, (hipStream_t)stream), who);
+  return check_hip(launch_attention(p, D, v_dtype, o_dtype, is_causal ? 1 : 0, (hipStream_t)stream, quantise_q), who);
 }
 
 struct VarlenLayout {
@@ -507,9 +515,9 @@ VarlenLayout varlen_layout(int B, int Hq, int Hkv, int total_q, int total_k, int
   auto take = [&](size_t n) { size_t at = o; o += align256(n); return at; };
   L.km = take((size_t)Hkv * D * 2);
   L.part = take(lbfa_mean_seq_workspace_bytes(1, Hkv, total_k, D));
-  L.q8 = take((size_t)total_q * Hq * D);
+  (void)total_q; (void)Hq; (void)max_q;  // Q is quantised inside the attention kernel
+  L.q8 = L.qs = 0;
   L.k8 = take((size_t)total_k * Hkv * D);
-  L.qs = take((size_t)B * Hq * ((max_q + LBFA_BLKQ - 1) / LBFA_BLKQ) * 4);
   L.ks = take((size_t)B * Hkv * ((max_k + LBFA_BLKK - 1) / LBFA_BLKK) * 4);
   L.total = o;
   return L;
@@ -553,11 +561,8 @@ int lbfa_forward_varlen(const void* q, const void* k, const void* v, int dtype, 
   if (!aligned16(workspace)) return fail(LBFA_EINVAL, "lbfa_forward_varlen: workspace must be 16-byte aligned");
   char* ws = (char*)workspace;
   void* km = smooth_k ? (void*)(ws + L.km) : nullptr;
-  int8_t* q8 = (int8_t*)(ws + L.q8);
   int8_t* k8 = (int8_t*)(ws + L.k8);
-  float* qs = (float*)(ws + L.qs);
   float* ks = (float*)(ws + L.ks);
-  const int64_t sq8[2] = {D, (int64_t)Hq * D};  // int8 codes: contiguous [tokens, H, D]
   const int64_t sk8[2] = {D, (int64_t)Hkv * D};
   int st;
   if (smooth_k) {  // km = k.mean(dim=0): over ALL tokens of the packed batch (src/core.py:453)
@@ -565,14 +570,14 @@ int lbfa_forward_varlen(const void* q, const void* k, const void* v, int dtype, 
     st = mean_impl(k, dtype, km, ws + L.part, lbfa_mean_seq_workspace_bytes(1, Hkv, total_k, D), 1, Hkv, total_k, D, Dg, sk3, stream);
     if (st) return st;
   }
-  st = quant_varlen_core("lbfa_forward_varlen (Q)", q, dtype, nullptr, 1, q8, qs, cu_seqlens_q, nullptr, sm_scale * 1.44269504f,
-                         q_qmax, LBFA_BLKQ, B, max_seqlen_q, Hq, D, Dg, strides_q, sq8, stream);
-  if (st) return st;
+  // Q is quantised by the attention kernel itself (blocks restart at every sequence start, as the quantiser's do)
+  if (!aligned16(q)) return fail(LBFA_EINVAL, "lbfa_forward_varlen: q must be 16-byte aligned");
   st = quant_varlen_core("lbfa_forward_varlen (K)", k, dtype, km, 1, k8, ks, cu_seqlens_k, nullptr, 1.0f, k_qmax, LBFA_BLKK, B,
                          max_seqlen_k, Hkv, D, Dg, strides_k, sk8, stream);
   if (st) return st;
-  return attn_varlen_core("lbfa_forward_varlen", q8, k8, v, dtype, o, dtype, qs, ks, cu_seqlens_q, cu_seqlens_k, nullptr, nullptr,
-                          B, Hq, Hkv, max_seqlen_q, max_seqlen_k, D, Dg, sq8, sk8, strides_v, strides_o, is_causal, stream);
+  return attn_varlen_core("lbfa_forward_varlen", (const int8_t*)q, k8, v, dtype, o, dtype, nullptr, ks, cu_seqlens_q, cu_seqlens_k,
+                          nullptr, nullptr, B, Hq, Hkv, max_seqlen_q, max_seqlen_k, D, Dg, strides_q, sk8, strides_v, strides_o,
+                          is_causal, stream, true, sm_scale * 1.44269504f, q_qmax);
 }
 
 }  // extern "C"

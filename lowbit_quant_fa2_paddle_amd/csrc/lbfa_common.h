@@ -113,6 +113,11 @@ struct AttnParams {
   const int* cu_kscale;
   int d_valid;  // channels >= d_valid of V / O are padding: V reads as 0, O is not written (o has d_valid columns)
   float qk_scale;  // un-quantised Q / K only: sm_scale * log2(e), applied to the fp32 scores
+  // Q quantised inside the attention kernel (one-call operators): q points at the fp16 / bf16 source (dtype = o's, strides in
+  // elements), each workgroup quantises its own 128-row block exactly as quant_per_block_kernel does (same codes and scale),
+  // and the LSE correction q . km comes from the same registers (q_dot_vec = km [B,Hkv,D] or null).
+  float q_sm_scale, q_qmax;
+  const unsigned short* q_dot_vec;
 };
 
 }  // namespace lbfa

@@ -6,7 +6,8 @@ import collections, csv, glob, json, os, shutil, sys
 tag, wl = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "c2")
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
-ks = glob.glob(f"{src}/kt/*/*_kernel_stats.csv")[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)  # gpurun merges runs: older files of the same tag may linger
+ks = newest(f"{src}/kt/*/*_kernel_stats.csv")
 shutil.copy(ks, f"profiles/{tag}_{wl}_kernel_stats.csv")
 out = {}
 for d in ("pmc1", "pmc2", "pmc3", "pmc4"):
@@ -14,7 +15,7 @@ for d in ("pmc1", "pmc2", "pmc3", "pmc4"):
     if not fs:
         continue
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(fs[0])):
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
         k = r["Kernel_Name"].split("(")[0]
         if "lbfa" in k:
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -24,7 +25,7 @@ for d in ("pmc1", "pmc2", "pmc3", "pmc4"):
     for k, v in acc.items():
         out.setdefault(k, {}).update({c: sum(x) / len(x) for c, x in v.items()})
 for k, v in out.items():
-    if "attn_fwd" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+    if "attn_fwd" in k and ", 3, " in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:  # QT = 3: the low-bit kernel
         v["hbm_bytes_per_launch"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
         if "GRBM_GUI_ACTIVE" in v and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
             cyc = v["GRBM_GUI_ACTIVE"] / 8
@@ -36,6 +37,6 @@ for k, v in out.items():
         json.dump(t, open(tj, "w"), indent=1)
 json.dump(out, open(f"profiles/{tag}_{wl}_pmc_summary.json", "w"), indent=1)
 for k, v in out.items():
-    if "attn_fwd" in k:
+    if "attn_fwd" in k and ", 3, " in k:
         print(k, json.dumps(v, indent=1))
 print(open(f"profiles/{tag}_{wl}_kernel_stats.csv").read()[:900])

@@ -74,6 +74,40 @@ def test_argument_validation_messages(lib):
     assert st == _lib.LBFA_EINVAL and b"workspace" in lib.lbfa_last_error()
 
 
+def test_one_call_and_varlen_validation(lib):
+    """The one-call, packed-varlen and un-quantised entry points reject bad arguments before any launch."""
+    from lowbit_quant_fa2_paddle_amd import _lib
+    buf = ctypes.create_string_buffer(1 << 16)
+    p = (ctypes.addressof(buf) + 255) & ~255
+    s3, s2 = _lib.strides3((1024, 512, 64)), _lib.strides2((64, 128))
+    # workspace sizes: pure functions; head dims that are multiples of 8 are accepted, others are not
+    need = lib.lbfa_forward_workspace_bytes(1, 2, 2, 8, 8, 64, 0, 1, 0)
+    assert need > 0 and lib.lbfa_forward_workspace_bytes(1, 2, 2, 8, 8, 80, 0, 1, 0) > need
+    assert lib.lbfa_forward_workspace_bytes(1, 2, 2, 8, 8, 36, 0, 1, 0) == 0
+    assert lib.lbfa_forward_varlen_workspace_bytes(2, 2, 2, 16, 16, 8, 8, 64) > 0
+    # lbfa_forward
+    st = lib.lbfa_forward(p, p, p, 0, p, None, p, need, 1, 2, 2, 8, 8, 36, s3, s3, s3, s3, 0.125, 127, 127, 0, 0, 1, None)
+    assert st == _lib.LBFA_EINVAL and b"Unsupported head_dim: 36" in lib.lbfa_last_error()
+    st = lib.lbfa_forward(p, p, p, 0, p, None, p, 16, 1, 2, 2, 8, 8, 64, s3, s3, s3, s3, 0.125, 127, 127, 0, 0, 1, None)
+    assert st == _lib.LBFA_EINVAL and b"workspace too small" in lib.lbfa_last_error()
+    st = lib.lbfa_forward(p, p, p, 0, p, None, p, need, 1, 3, 2, 8, 8, 64, s3, s3, s3, s3, 0.125, 127, 127, 0, 0, 1, None)
+    assert st == _lib.LBFA_EINVAL and b"divisible" in lib.lbfa_last_error()
+    # packed batches
+    st = lib.lbfa_forward_varlen(p, p, p, 0, p, None, p, p, 1 << 15, 2, 2, 2, 16, 16, 8, 8, 64, s2, s2, s2, s2, 0.125, 127, 127, 0, 1, None)
+    assert st == _lib.LBFA_EINVAL and b"null pointer" in lib.lbfa_last_error()
+    st = lib.lbfa_forward_varlen(p, p, p, 0, p, p, p, p, 1 << 15, 2, 2, 2, 16, 16, 8, 8, 136, s2, s2, s2, s2, 0.125, 127, 127, 0, 1, None)
+    assert st == _lib.LBFA_EINVAL and b"Unsupported head_dim: 136" in lib.lbfa_last_error()
+    st = lib.lbfa_quant_per_block_varlen(p, 0, None, 1, p, p, p, None, 1.0, 127, 128, 2, 8, 2, 64, s2, s2, None)
+    assert st == _lib.LBFA_EINVAL and b"null pointer" in lib.lbfa_last_error()
+    st = lib.lbfa_attn_fwd_varlen(p, p, p, 2, p, 0, p, p, p, p, p, p, 2, 2, 2, 8, 8, 64, s2, s2, s2, s2, 0, None)
+    assert st == _lib.LBFA_EINVAL and b"float16 or bfloat16" in lib.lbfa_last_error()
+    # un-quantised kernel
+    st = lib.lbfa_sdpa_fwd(p, p, p, 0, p, None, 1, 2, 2, 8, 16, 64, s3, s3, s3, s3, 0.125, 1, None)
+    assert st == _lib.LBFA_EINVAL and b"qo_len and kv_len must be equal" in lib.lbfa_last_error()
+    st = lib.lbfa_sdpa_fwd(p, p, p, 2, p, None, 1, 2, 2, 8, 8, 64, s3, s3, s3, s3, 0.125, 0, None)
+    assert st == _lib.LBFA_EINVAL and b"float16 or bfloat16" in lib.lbfa_last_error()
+
+
 def test_api_surface_matches_reference():
     """Every name the reference package exports (src/__init__.py:1-17) is importable from the package root."""
     import lowbit_quant_fa2_paddle_amd as lb

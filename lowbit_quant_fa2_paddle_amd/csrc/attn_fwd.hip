@@ -26,7 +26,7 @@
 // LDS images (bank-conflict-free for the access patterns above):
 //   K tile  [64 keys][D bytes]   16-B chunk c of row r stored at chunk c ^ kx(r)
 //   V tile  [64 keys][D fp16]    64-B chunk c of row r stored at chunk c ^ vx(r)
-//   V fp8   [D][64 bytes]        already swizzled in HBM by lbfa_quant_v_fp8 -> linear copy
+//   V fp8   [D][64 bytes]        keys permuted into MFMA k order and 16-B chunks swizzled in HBM by lbfa_quant_v_fp8 -> linear copy
 #include "attn_common.h"
 
 namespace lbfa {
@@ -43,6 +43,9 @@ namespace lbfa {
 #ifndef LBFA_THR
 #define LBFA_THR 8.0f
 #endif
+// fp8 PV: O^T += V^T P^T with ONE v_mfma_scale_f32_32x32x64_f8f6f4 per 32 channels and 64-key tile (e4m3 operands, unit
+// block scales: twice the fp16 MFMA rate) - must match the V layout written by lbfa_quant_v_fp8 (quant_kernels.hip)
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 // Row sums of a 64-key tile through the matrix pipe: O_l^T = 1 P^T with an all-ones A operand - every
 // accumulator row is the column sum of P^T over both lane halves.
@@ -180,30 +183,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     qsc = scale;
     const float rcp = 1.0f / scale;
     const bool exact_rcp_ok = (__builtin_amdgcn_readfirstlane(__float_as_uint(scale)) & 0x7fffffu) != 0x7fffffu;
+    auto encode = [&](auto fast_tag) {  // block-uniform choice, two straight-line instances (as in quant_kernels.hip)
+      constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      unsigned w[4];
+      for (int s = 0; s < KS; ++s) {
+        unsigned w[4];
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        int qv[4];
+        for (int g4 = 0; g4 < 4; ++g4) {
+          int qv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float xv = xs[s][4 * g4 + e];
-          float y;
-          if (exact_rcp_ok) {  // Markstein: RN(x / scale) from the correctly rounded reciprocal (see quant_kernels.hip)
-            const float q0 = xv * rcp;
-            y = __builtin_fmaf(__builtin_fmaf(-q0, scale, xv), rcp, q0);
-          } else {
-            y = xv / scale;
+          for (int e = 0; e < 4; ++e) {
+            const float xv = xs[s][4 * g4 + e];
+            float y;
+            if constexpr (FAST) {  // Markstein: RN(x / scale) from the correctly rounded reciprocal (see quant_kernels.hip)
+              const float q0 = xv * rcp;
+              y = __builtin_fmaf(__builtin_fmaf(-q0, scale, xv), rcp, q0);
+            } else {
+              y = xv / scale;
+            }
+            qv[e] = (int)(y + __builtin_copysignf(0.5f, y));
           }
-          qv[e] = (int)(y + __builtin_copysignf(0.5f, y));
+          const unsigned p01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(qv[0], qv[1]));
+          const unsigned p23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(qv[2], qv[3]));
+          w[g4] = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
         }
-        const unsigned p01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(qv[0], qv[1]));
-        const unsigned p23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(qv[2], qv[3]));
-        w[g4] = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
+        qf[s] = i32x4{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
       }
-      qf[s] = i32x4{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
-    }
+    };
+    if (exact_rcp_ok) encode(std::true_type{});
+    else encode(std::false_type{});
   } else {
     const char* qbase = (const char*)p.q + ESZ * (q_off + (int64_t)h * p.qh);
     const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(qbase, (unsigned)(ESZ * ((int64_t)(Sq - 1) * p.qs + dq_valid)));
@@ -258,12 +266,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) kf_base[s] = kf_lane ^ (s << 5);
   }
-  constexpr int NVB = FP8 ? 4 : DB;
-  unsigned vf_base[NVB];  // f16: [db] + ks*16*2D + hi*8*2D ;  fp8: [ks] + db*32*64
+  constexpr int NVB = FP8 ? 1 : DB;
+  unsigned vf_base[NVB];  // f16: [db] + ks*16*2D + hi*8*2D ;  fp8: + db*32*64, second 16-B chunk at ^ 16
 #pragma unroll
   for (int i = 0; i < NVB; ++i) {
     if constexpr (FP8) {
-      vf_base[i] = 2 * KBYTES + r * 64 + (((2 * i + hh) ^ ((r >> 2) & 7)) << 3);
+      // channel row r (+ 32 db) of the [D][64] image, this lane's 32 keys = 16-B chunks 2hh and 2hh+1, chunk c stored at c ^ ((r>>2)&3)
+      vf_base[i] = 2 * KBYTES + r * 64 + (((2 * hh) ^ ((r >> 2) & 3)) << 4);
     } else {
       const int vrow = 4 * hh + ((lane & 15) >> 2);
       const int vcol = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
@@ -421,6 +430,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     constexpr bool ONES = LAZY && (LBFA_ONES_SUM != 0) && (D == 64);
     typedef typename std::conditional<FP8, long, f16x8>::type pfrag_t;
     pfrag_t pf[4];
+    i32x8 pf8;  // fp8: all 32 P values of the lane = one B operand (k = 32 hh + 16 kb2 + i)
     float tile_sum = 0.f;
     auto exponentiate = [&]() {  // x <- P in place, pf <- packed P^T fragments, tile_sum <- row sum of the tile
       float c1 = c0 - m_run;  // exact (grid argument above); +inf while m_run = -inf
@@ -442,7 +452,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
           w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[kb2][rb + 2], x[kb2][rb + 3], w0, true);
           w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[kb2][rb + 4], x[kb2][rb + 5], w1, false);
           w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[kb2][rb + 6], x[kb2][rb + 7], w1, true);
-          pf[ks] = (long)(((unsigned long)w1 << 32) | (unsigned long)w0);
+          pf8[2 * ks] = (int)w0;
+          pf8[2 * ks + 1] = (int)w1;
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) pf[ks][e] = (_Float16)x[kb2][rb + e];
@@ -497,18 +508,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #if LBFA_PRIO & 2
     __builtin_amdgcn_s_setprio(1);
 #endif
-    static_for<0, NMF>([&](auto i) {
-      constexpr int idx = decltype(i)::value;
-      constexpr int ks = idx / DB, db = idx % DB;
-      if constexpr (FP8) {
-        const long vf = *reinterpret_cast<const long*>(vbuf + vf_base[ks] + db * 2048);
-        acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf, pf[ks], acc_o[db], 0, 0, 0);
-      } else {
+    if constexpr (FP8) {
+      static_for<0, DB>([&](auto i) {
+        constexpr int db = decltype(i)::value;
+        const i32x4 v0 = *reinterpret_cast<const i32x4*>(vbuf + vf_base[0] + db * 2048);
+        const i32x4 v1 = *reinterpret_cast<const i32x4*>(vbuf + (vf_base[0] ^ 16u) + db * 2048);
+        const i32x8 vf = i32x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        // e4m3 x e4m3 (cbsz = blgp = 0), E8M0 block scales 0x7F = 2^0
+        acc_o[db] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf8, acc_o[db], 0, 0, 0, 0x7F, 0, 0x7F);
+      });
+      // Toolchain work-around (ROCm 7.2 / clang 22): the wait states the compiler leaves between this 16-pass MFMA and
+      // a VALU read of its result (register copies at control-flow edges, the epilogue) are too few - the last two
+      // accumulator registers were read stale (tests: odd tile counts).  LBFA_MX_NOP more wait states close the gap.
+#ifndef LBFA_MX_NOP
+#define LBFA_MX_NOP 7
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop %0" ::"n"(LBFA_MX_NOP));
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      static_for<0, NMF>([&](auto i) {
+        constexpr int idx = decltype(i)::value;
+        constexpr int ks = idx / DB, db = idx % DB;
         if constexpr (idx + NPRE < NMF) v_request(std::integral_constant<int, idx + NPRE>{});
         const f16x8 vf = f16x8{vlo[idx][0], vlo[idx][1], vlo[idx][2], vlo[idx][3], vhi[idx][0], vhi[idx][1], vhi[idx][2], vhi[idx][3]};
         acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ks], acc_o[db], 0, 0, 0);
-      }
-    });
+      });
+    }
 #if LBFA_PRIO & 2
     __builtin_amdgcn_s_setprio(0);
 #endif

@@ -209,14 +209,15 @@ struct VFp8Params {
   int d_valid;  // channels >= d_valid are padding: not read, encoded as 0
 };
 
-// key permutation inside a 64-key tile: position -> key.  The MFMA B-operand built from the S^T
-// accumulator holds, for k-step ks (16 keys) and lane half hh, keys 16ks + 8(j>>2) + 4hh + (j&3),
-// j = 0..7 (cdna_hip_programming.md "An accumulator tile as the next MFMA's operand").  Storing V^T with
-// the keys of (ks, hh) contiguous lets the A operand be fetched with one 8-byte LDS read.
+// key permutation inside a 64-key tile: key -> byte position in the channel's 64-byte row.  The attention kernel
+// feeds ALL 32 P values a lane holds (from the S^T accumulators: keys 32 kb2 + 8 g + 4 hh + e, kb2 < 2, g < 4, e < 4) to
+// one v_mfma_scale_f32_32x32x64_f8f6f4 as the B operand, whose lane (r, hh) supplies k = 32 hh + j, j = 16 kb2 + 4 g + e
+// (layout probed with exact integer data, tools/mfma_probe.hip).  Storing V^T with that k order lets the A operand be
+// fetched with two 16-byte LDS reads.
 __device__ __forceinline__ int vfp8_pos_of_key(int key) {
-  const int ks = key >> 4, w = key & 15;
-  const int j = ((w >> 3) << 2) | (w & 3), hh = (w >> 2) & 1;
-  return ks * 16 + hh * 8 + j;
+  const int kb2 = key >> 5, w = key & 31;
+  const int g = w >> 3, hh = (w >> 2) & 1, e = w & 3;
+  return 32 * hh + 16 * kb2 + 4 * g + e;
 }
 
 template <int DT, int D>
@@ -282,10 +283,10 @@ __global__ __launch_bounds__(256) void v_encode_kernel(VFp8Params p) {
       const float v = load_cvt<DT>((unsigned short)((i & 1) ? (w[i >> 1] >> 16) : (w[i >> 1] & 0xffffu))) * inv[i];
       // v_cvt_pk_fp8_f32: OCP e4m3fn on gfx950, RNE, saturating
       const unsigned pk = __builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0u, false);
-      // 8-byte slot XOR-swizzled by the channel so the attention kernel's ds_read_b64 of 32 channels
-      // x one slot is bank-conflict-free (row stride 64 B -> 4 rows per 256-B bank window).
+      // 16-byte chunk XOR-swizzled by the channel so the attention kernel's ds_read_b128 of 16 channels x one
+      // chunk is bank-conflict-free (row stride 64 B -> 4 rows per 256-B bank window).
       const int d = c * 8 + i;
-      tile[d][pos ^ (((d >> 2) & 7) << 3)] = (uint8_t)(pk & 0xffu);
+      tile[d][(((pos >> 4) ^ ((d >> 2) & 3)) << 4) | (pos & 15)] = (uint8_t)(pk & 0xffu);
     }
   }
   __syncthreads();

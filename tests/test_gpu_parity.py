@@ -198,6 +198,10 @@ def test_operator_int4(oracle, dev, q_bits, causal):
     (2, 4, 2, 384, 128, "NHD", True, "fp16"),
     (1, 2, 2, 333, 128, "HND", False, "bf16"),
     (1, 2, 2, 200, 64, "NHD", True, "fp16"),
+    # odd numbers of 64-key tiles (the block-scaled MFMA's result was once read too early on that path)
+    (1, 2, 2, 64, 64, "HND", False, "fp16"),
+    (2, 2, 1, 192, 128, "HND", False, "fp16"),
+    (1, 2, 2, 320, 128, "NHD", False, "bf16"),
 ])
 def test_operator_int8_fp8_vs_oracle(oracle, dev, B, H, Hkv, S, D, layout, causal, dtype):
     """fp8-PV: the oracle restates CUDA code that cannot run here and the reference holds no fixture -
@@ -232,11 +236,11 @@ def test_v_fp8_quant_exact(oracle, dev):
     tiles = raw[: B * H * ntile * D * 64].reshape(B, H, ntile, D, 64)
     codes = oracle.e4m3fn_encode(ref8)  # [B,H,S,D]
     got = np.zeros((B, H, ntile * 64, D), np.uint8)
-    for key in range(64):
-        ks_, w = key >> 4, key & 15
-        pos = ks_ * 16 + ((w >> 2) & 1) * 8 + (((w >> 3) << 2) | (w & 3))
+    for key in range(64):  # device layout (include/lowbit_fa.h: "a device detail"): MFMA k order + 16-byte chunk swizzle
+        kb2, w = key >> 5, key & 31
+        pos = 32 * ((w >> 2) & 1) + 16 * kb2 + 4 * (w >> 3) + (w & 3)
         for d in range(D):
-            got[:, :, key::64, d][:, :, :ntile] = tiles[:, :, :, d, pos ^ (((d >> 2) & 7) << 3)]
+            got[:, :, key::64, d][:, :, :ntile] = tiles[:, :, :, d, (((pos >> 4) ^ ((d >> 2) & 3)) << 4) | (pos & 15)]
     assert np.array_equal(got[:, :, :S], codes)
     assert np.all(got[:, :, S:] == 0)
 

@@ -7,9 +7,12 @@ out=variants/lib_$name.so
 mkdir -p variants /tmp/lbfa_var_$name
 C=lowbit_quant_fa2_paddle_amd/csrc
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt $extra"
+rm -f /tmp/lbfa_var_$name/*.o $out
+pids=""
 for f in lbfa_api quant_kernels attn_fwd; do
   /opt/rocm/bin/hipcc $FLAGS -c $C/$f.hip -o /tmp/lbfa_var_$name/$f.o &
+  pids="$pids $!"
 done
-wait
+for p in $pids; do wait $p; done   # set -e: a failed compile stops here
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out /tmp/lbfa_var_$name/*.o
 echo built $out

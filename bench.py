@@ -166,7 +166,8 @@ def main():
 
     kern_ms = sum(ev[0].elapsed_time(ev[1]) for ev in attn_events) / max(len(attn_events), 1)
     achieved = flops_rank / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-    peak = PEAK_MIX_TF
+    # fp8 PV runs on the block-scaled MFMA (2x the fp16 rate = the int8 rate): both halves of the FLOPs at 5 PFLOP/s
+    peak = PEAK_I8_TF if api == "int8_fp8" else PEAK_MIX_TF
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per launch from rocprofv3 --pmc passes
     if os.path.exists(tf):
@@ -249,7 +250,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "kernel": "attn_fwd_kernel", "kernel_ms": round(kern_ms, 4),
-                         "peak_note": "mixed roof 1/(0.5/5000 + 0.5/2500): half the FLOPs int8 MFMA, half fp16 MFMA"},
+                         "peak_note": ("int8 MFMA for QK^T and block-scaled e4m3 MFMA for PV: 5000 both" if api == "int8_fp8" else
+                                       "mixed roof 1/(0.5/5000 + 0.5/2500): half the FLOPs int8 MFMA, half fp16 MFMA")},
             "cpu_baseline": cpu,
             "fa2_reference": fa2,
         }

@@ -71,15 +71,40 @@ def all_gather_batch(o, dim: int = 0, group=None):
     return out if dim == 0 else out.transpose(0, dim)
 
 
-def sharded_attention(fn: Callable, q, k, v, *, tensor_layout: str = "HND", gather: bool = True, group=None, **kwargs):
+def _pipelined_batch_gather(fn, qs, ks, vs, tensor_layout, world, group, kwargs):
+    """Batch-sharded run with the gather hidden behind the compute: the local shard is processed one batch element
+    at a time, and each finished element is all-gathered asynchronously (RCCL works on its own stream) while the
+    next element's kernels run.  On the xGMI mesh a direct all-gather moves one peer's piece per link, so a piece of
+    B/world/nb of the output costs 1/nb of the link time and only the last piece is exposed.
+    Needs equal shards; returns the full [B, ...] output in rank-major batch order (= the unsharded order)."""
+    import torch
+    import torch.distributed as dist
+    nb = qs.shape[0]
+    out = None
+    handles = []
+    for i in range(nb):
+        o_i = fn(qs[i:i + 1], ks[i:i + 1], vs[i:i + 1], tensor_layout=tensor_layout, **kwargs)
+        if out is None:
+            out = torch.empty((world, nb) + tuple(o_i.shape[1:]), dtype=o_i.dtype, device=o_i.device)
+        handles.append(dist.all_gather([out[r, i:i + 1] for r in range(world)], o_i.contiguous(), group=group, async_op=True))
+    for h in handles:
+        h.wait()
+    return out.reshape((world * nb,) + tuple(out.shape[2:]))
+
+
+def sharded_attention(fn: Callable, q, k, v, *, tensor_layout: str = "HND", gather: bool = True, group=None,
+                      overlap: bool = False, **kwargs):
     """Run `fn` (one of the lowbit_fa_* operators) on this rank's shard of replicated q, k, v.
-    gather=True: return the full output on every rank (one all-gather); False: return the local shard."""
+    gather=True: return the full output on every rank (one all-gather); False: return the local shard.
+    overlap=True (batch sharding with equal shards, no lse): gather piecewise behind the compute."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world == 1:
         return fn(q, k, v, tensor_layout=tensor_layout, **kwargs)
     qs, ks, vs, spec = shard_inputs(q, k, v, tensor_layout, world, rank)
+    if gather and overlap and spec == "batch" and q.shape[0] % world == 0 and not kwargs.get("return_lse", False):
+        return _pipelined_batch_gather(fn, qs, ks, vs, tensor_layout, world, group, kwargs)
     out = fn(qs, ks, vs, tensor_layout=tensor_layout, **kwargs)
     if not gather:
         return out

@@ -40,6 +40,9 @@ def _worker(rank, world, port, B, H, Hkv, S, D, layout, causal, ret):
         assert torch.equal(lse, full_lse)
         qs, _, _, spec = lbd.shard_inputs(tq, tk, tv, layout, world, rank)
         assert o_local.shape == qs.shape
+        # gather hidden behind the compute (piecewise async all-gather); falls back to the plain path when it cannot apply
+        o_pipe = lbd.sharded_attention(_oracle_op, tq, tk, tv, tensor_layout=layout, is_causal=causal, overlap=True)
+        assert torch.equal(o_pipe, full_o), "pipelined gather differs from the unsharded result"
         ret[rank] = spec
     finally:
         dist.destroy_process_group()

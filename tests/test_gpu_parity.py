@@ -406,3 +406,33 @@ def test_head_dims_padded_inside_the_kernels(oracle, dev, D, layout, causal, pv)
     pq, pk, pv_ = (torch.nn.functional.pad(t, (0, pad)) for t in (tq, tk, tv))
     o_p = fn(pq, pk, pv_, tensor_layout=layout, is_causal=causal, sm_scale=D ** -0.5)[..., :D]
     assert torch.equal(o, o_p)
+
+
+@pytest.mark.parametrize("pv", ["fp16", "fp8"])
+def test_operator_is_hipgraph_capturable(oracle, dev, pv):
+    """Every launch of the one-call path is asynchronous on the caller's stream (no host sync, no host read of device
+    data), so the operator can be captured into a hipGraph (torch.cuda.CUDAGraph) and replayed on new inputs."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    fn = lb.lowbit_fa_qk_int8_pv_fp16_triton if pv == "fp16" else lb.lowbit_fa_qk_int8_pv_fp8_cuda
+    q, k, v = oracle.make_inputs(2, 4, 320, 64, seed=3, k_bias=0.2)
+    sq, sk, sv = (_t(a, "fp16", dev) for a in (q, k, v))
+    eager = fn(sq, sk, sv, is_causal=True, return_lse=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # warm-up on the capture stream
+        fn(sq, sk, sv, is_causal=True, return_lse=True)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fn(sq, sk, sv, is_causal=True, return_lse=True)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], eager[0]) and torch.equal(out[1], eager[1])
+    # new data in the captured input buffers
+    q2, k2, v2 = oracle.make_inputs(2, 4, 320, 64, seed=4, k_bias=-0.3)
+    for dst, src in ((sq, q2), (sk, k2), (sv, v2)):
+        dst.copy_(_t(src, "fp16", dev))
+    g.replay()
+    torch.cuda.synchronize()
+    eager2 = fn(sq, sk, sv, is_causal=True, return_lse=True)
+    assert torch.equal(out[0], eager2[0]) and torch.equal(out[1], eager2[1])

@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     if constexpr (decltype(masked_tag)::value && CAUSAL) skip = j * 64 > row0 + 31;  // all keys above all rows of this wave
     if (!skip) compute_tile(buf_tag, j, masked_tag);
     store_tile(nbuf_tag);
-    __syncthreads();
+    __syncthreads();  // measured: dropping every per-tile barrier (wrong results, timing only) gains 0.8 % at D=64, 3.8 % at D=128
   };
 
   load_tile(0);

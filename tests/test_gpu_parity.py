@@ -436,3 +436,22 @@ def test_operator_is_hipgraph_capturable(oracle, dev, pv):
     torch.cuda.synchronize()
     eager2 = fn(sq, sk, sv, is_causal=True, return_lse=True)
     assert torch.equal(out[0], eager2[0]) and torch.equal(out[1], eager2[1])
+
+
+def test_c_abi_without_any_framework(dev):
+    """examples/cabi_demo.cpp: a plain C++ host (hipMalloc + ONE lbfa_forward call, no torch / Python in the process)
+    built against include/lowbit_fa.h, checked against exact fp32 attention on the host."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    exe = os.path.join("/tmp", f"cabi_demo_{os.getpid()}")
+    pkg = os.path.join(ROOT, "lowbit_quant_fa2_paddle_amd")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", os.path.join(ROOT, "examples", "cabi_demo.cpp"),
+                    "-I" + os.path.join(ROOT, "include"), "-L" + pkg, "-llowbit_fa_hip", "-Wl,-rpath," + pkg, "-o", exe],
+                   check=True, capture_output=True, timeout=600)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr

@@ -112,3 +112,16 @@ def test_varlen_validation(dev):
     with pytest.raises(AssertionError):
         lb.sageattn_varlen(x.float(), x.float(), x.float(), cu, cu, 64, 64)
     assert tuple(lb.sageattn_varlen(x[:0], x, x, cu, cu, 64, 64).shape) == (0, 2, 64)
+
+
+def test_varlen_empty_sequences(oracle, dev):
+    """Zero-length sequences inside a packed batch: an empty query range produces nothing, an empty key range zeros
+    (the reference starts from l = 1, acc = 0: attn_qk_int8_block_varlen.py:171-173,195)."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    lens_q, lens_k = [64, 0, 100, 50], [64, 0, 100, 0]
+    q, k, v, cu_q, cu_k = oracle.make_varlen_inputs(lens_q, lens_k, 2, 2, 64, seed=8, k_bias=0.2)
+    tq, tk, tv = (_t(a, "fp16", dev) for a in (q, k, v))
+    o = lb.sageattn_varlen(tq, tk, tv, torch.from_numpy(cu_q).to(dev), torch.from_numpy(cu_k).to(dev), max(lens_q), max(lens_k))
+    ref = oracle.lowbit_fa_varlen(q, k, v, cu_q, cu_k, tail="neg_inf", amax_floor=1e-7)
+    _o_close(_np(o), ref, "fp16")
+    assert float(np.abs(_np(o)[cu_q[3]:]).max()) == 0.0

@@ -103,12 +103,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE=1 here)")
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # LBFA_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box): ranks share the visible devices round-robin and rendezvous
+    # over gloo - RCCL cannot place two ranks on one device.  The driver's multi-GPU runs use one GPU per rank + nccl.
+    share = os.environ.get("LBFA_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     api, B, H, Hkv, S, D, layout, causal, extra, desc = WORKLOADS[args.workload]
     fn = {"int8_fp16": lb.lowbit_fa_qk_int8_pv_fp16_triton, "int4_fp16": lb.lowbit_fa_qk_int4_pv_fp16_triton,
@@ -157,7 +164,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if distributed:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3

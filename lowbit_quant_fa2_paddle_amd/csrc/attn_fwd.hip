@@ -68,8 +68,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   static_assert(!QQ || QT == kQInt8, "in-kernel Q quantisation belongs to the int8 path");
   constexpr bool FP8 = (VT == LBFA_E4M3);
   // QT = kQInt8: the low-bit path.  QT = LBFA_F16 / LBFA_BF16: un-quantised Q and K (the FP16 branch of the
-  // precision router, src/core.py:1066-1096): same tiling and softmax, scores from v_mfma_f32_32x32x16_f16 on fp16
-  // tiles (bf16 is converted on the way in, like V), K rows are 2 D bytes.
+  // precision router, src/core.py:1066-1096): same tiling and softmax, scores from v_mfma_f32_32x32x16_f16 / _bf16 on
+  // 16-bit tiles (K rows are 2 D bytes); P and V stay fp16 (bf16 V is converted on the way in, as in the low-bit path).
   constexpr bool QK16 = (QT != kQInt8);
   constexpr int ESZ = QK16 ? 2 : 1;                  // bytes per Q / K element
   constexpr int RB = D * ESZ;                        // bytes per K row
@@ -219,7 +219,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     for (int s = 0; s < KS; ++s) {
       const unsigned col_b = 16 * hh + 32 * s;  // byte column
       u32x4 raw = buf_load16(q_rs, col_b < (unsigned)(ESZ * dq_valid) ? ESZ * (unsigned)qrow * (unsigned)p.qs + col_b : 0x80000000u, 0);
-      if constexpr (QT == LBFA_BF16) raw = bf16x8_to_f16x8(raw);
       qf[s] = __builtin_bit_cast(i32x4, raw);
     }
     if constexpr (!QK16) qsc = p.q_scale[qsc_base + (int64_t)h * p.qsc_h + (int64_t)qt * p.qsc_blk];
@@ -296,7 +295,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int i = 0; i < KCH; ++i) {
       u32x4 val = kreg[i];
-      if constexpr (QT == LBFA_BF16) val = bf16x8_to_f16x8(val);
       *reinterpret_cast<u32x4*>(smem + k_loff + i * K_LSTEP + BUF * KBYTES) = val;
     }
 #pragma unroll
@@ -372,7 +370,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         for (int s = 0; s < KS; ++s) {
           const unsigned kfa = KF_XOR ? (kf_lane ^ (unsigned)(s << 5)) : kf_base[KF_XOR ? 0 : s];
           const i32x4 kf = *reinterpret_cast<const i32x4*>(kbuf + kfa + kb2 * 32 * RB);
-          if constexpr (QK16) {
+          if constexpr (QT == LBFA_BF16) {  // bf16 Q / K go to the bf16 MFMA as they are: exact products, full bf16 range
+            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            const bf16x8 ka = __builtin_bit_cast(bf16x8, kf), qb = __builtin_bit_cast(bf16x8, qf[s]);
+            if (s == 0) facc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qb, f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+            else facc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qb, facc, 0, 0, 0);
+          } else if constexpr (QK16) {
             const f16x8 ka = __builtin_bit_cast(f16x8, kf), qb = __builtin_bit_cast(f16x8, qf[s]);
             if (s == 0) facc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qb, f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
             else facc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qb, facc, 0, 0, 0);

@@ -55,3 +55,17 @@ def test_fp16_kernel_validation(dev):
     with pytest.raises(AssertionError):
         core.flash_attn_fp16(x, x[:, :, :32], x[:, :, :32], is_causal=True)
     assert tuple(core.flash_attn_fp16(x[:, :, :0], x, x).shape) == (1, 2, 0, 64)
+
+
+def test_bf16_inputs_keep_their_range(oracle, dev):
+    """bf16 Q / K go to the bf16 MFMA unconverted: magnitudes beyond the fp16 range (here a 7e4 offset on a key
+    channel the queries ignore) must not turn into inf * 0 = NaN."""
+    from lowbit_quant_fa2_paddle_amd import core
+    q, k, v = oracle.make_inputs(1, 2, 200, 64, seed=6, dtype="bf16")
+    q[..., 0] = 0.0
+    k[..., 0] = 70144.0  # exactly representable in bf16, > 65504
+    tq, tk, tv = (_t(a, "bf16", dev) for a in (q, k, v))
+    o = core.flash_attn_fp16(tq, tk, tv)
+    assert torch.isfinite(o).all()
+    ref = oracle.sdpa_naive(*(a.astype(np.float64) for a in (q, k, v)), sm_scale=64 ** -0.5)
+    _o_close(_np(o), ref, "bf16")

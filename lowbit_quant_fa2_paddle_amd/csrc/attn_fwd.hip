@@ -34,6 +34,9 @@ namespace lbfa {
 #ifndef LBFA_PRIO
 #define LBFA_PRIO 2  // s_setprio(1) around the PV MFMA section: keeps the matrix pipe fed while other waves exponentiate (+3..6 %)
 #endif
+#ifndef LBFA_PRIO_FP8
+#define LBFA_PRIO_FP8 0  // fp8 PV (2 / 4 long block-scaled MFMAs per tile): measured best without it (+2.7 % C5, +4 % D=64)
+#endif
 #ifndef LBFA_VPRE
 #define LBFA_VPRE(D) 0  // measured: prefetch distances 2..8 change nothing beyond noise (other waves already hide the LDS latency)
 #endif
@@ -75,6 +78,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   constexpr int RB = D * ESZ;                        // bytes per K row
   // fp8 P is scaled so that its maximum is 448 = e4m3 max (attn_utils.cuh:30): no headroom to defer
   constexpr float THR = FP8 ? 0.0f : LBFA_THR;
+  constexpr int PRIO = FP8 ? LBFA_PRIO_FP8 : LBFA_PRIO;
   constexpr int KS = RB / 32;                        // k-steps of the score product (32 int8 or 16 fp16 per MFMA)
   constexpr int DB = D / 32;                         // 32-channel blocks of O^T
   constexpr int KBYTES = 64 * RB;                    // K tile
@@ -359,9 +363,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     float x[2][16];  // scores as floats kMagic + s (accumulator bits), then overwritten in place by P
     // -- S^T = K Q^T (int8 -> int32, biased by kMagic): two 32-key blocks
     auto compute_scores = [&]() {
-#if LBFA_PRIO & 1
-      __builtin_amdgcn_s_setprio(1);
-#endif
+      if constexpr (PRIO & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
         i32x16 sacc;
@@ -398,9 +400,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
           x[kb2][i] = tv;
         }
       }
-#if LBFA_PRIO & 1
-      __builtin_amdgcn_s_setprio(0);
-#endif
+      if constexpr (PRIO & 1) __builtin_amdgcn_s_setprio(0);
     };
     // Move the reference m_run up to (at least) this tile's row max, rescaling O and l, when some row of the
     // wave needs it.  First tile: m_run = -inf -> alpha = 0.
@@ -508,9 +508,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     else l_run += half_swap_sum(tile_sum);
 
     // -- O^T += V^T P^T : P^T fragments straight from the score accumulators
-#if LBFA_PRIO & 2
-    __builtin_amdgcn_s_setprio(1);
-#endif
+    if constexpr (PRIO & 2) __builtin_amdgcn_s_setprio(1);
     if constexpr (FP8) {
       static_for<0, DB>([&](auto i) {
         constexpr int db = decltype(i)::value;
@@ -538,9 +536,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ks], acc_o[db], 0, 0, 0);
       });
     }
-#if LBFA_PRIO & 2
-    __builtin_amdgcn_s_setprio(0);
-#endif
+    if constexpr (PRIO & 2) __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- tile loop: one barrier per tile, buffers alternate statically (loop unrolled by two).

@@ -220,6 +220,13 @@ __device__ __forceinline__ int vfp8_pos_of_key(int key) {
   return 32 * hh + 16 * kb2 + 4 * g + e;
 }
 
+// zeroes the amax scratch (a kernel rather than hipMemsetAsync: a memset node captured into a hipGraph did not
+// re-run reliably on replay - tests/test_gpu_parity.py::test_operator_is_hipgraph_capturable[fp8])
+__global__ void zero_u32_kernel(unsigned* p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
 template <int DT, int D>
 __global__ __launch_bounds__(256) void v_amax_kernel(VFp8Params p) {
   // channel amax over the tokens of one split (fused.cu:391-394); max is order-independent, so the
@@ -368,8 +375,10 @@ hipError_t launch_quant_v_fp8(const void* v, int dtype, uint8_t* out, float* v_s
   p.B = B; p.H = H; p.S = S; p.ntile = (S + 63) / 64;
   p.rows_per_split = 512;
   const int nsplit = (S + p.rows_per_split - 1) / p.rows_per_split;
-  hipError_t e = hipMemsetAsync(p.amax_bits, 0, (size_t)B * H * D * sizeof(unsigned), stream);
-  if (e != hipSuccess) return e;
+  {
+    const int64_t n = (int64_t)B * H * D;
+    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p.amax_bits, n);
+  }
   dim3 g1(nsplit, H, B), g2(p.ntile, H, B);
 #define LBFA_V(DT, DD)                                                               \
   hipLaunchKernelGGL((v_amax_kernel<DT, DD>), g1, dim3(256), 0, stream, p);          \

@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       // Only if a sum blew up (first tile: reference = -inf -> +inf) redo the tile the long way: recompute the
       // scores (K is still in LDS), take the row max, move the reference, exponentiate again.  Written as a
       // loop so the rare second pass reuses the same code and registers.
-      bool redo = false;
+      bool redo = (j == 0);  // first tile: the reference is still -inf, the attempt could only overflow - go the long way at once
 #pragma clang loop unroll(disable)
       for (;;) {
         compute_scores();

@@ -144,6 +144,57 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     v_tile_stride = 128 * p.vs;
   }
 
+  // ---- loop-invariant per-thread offsets: global (voffset) and LDS -----------------------------------
+  // Chunk i of a thread is chunk 0 moved down by a whole number of rows (KROWS / VROWS per pass), which leaves the
+  // swizzles unchanged: one voffset / LDS offset per operand, the rest is a scalar soffset and a ds immediate.
+  constexpr int KCPR = RB / 16, KROWS = 256 / KCPR;              // K: 16-B chunks per row, rows per pass
+  constexpr int VCPR = FP8 ? 1 : D / 8, VROWS = FP8 ? 0 : 256 / VCPR;
+  unsigned k_goff, k_loff, v_goff, v_loff;
+  {
+    const int row = t / KCPR, ch = t % KCPR;
+    // padded channels: an offset beyond any window -> the range check returns zeros (windows are < 2 GiB, checked by the C ABI)
+    k_goff = ch * 16 < ESZ * dq_valid ? ESZ * (unsigned)row * (unsigned)p.ks + ch * 16 : 0x80000000u;
+    k_loff = row * RB + ((ch ^ kx<RB>(row)) << 4);
+  }
+  if constexpr (FP8) {
+    v_goff = t * 16;
+    v_loff = 2 * KBYTES + t * 16;
+  } else {
+    const int row = t / VCPR, ch = t % VCPR;
+    v_goff = ch * 8 < p.d_valid ? 2 * ((unsigned)row * (unsigned)p.vs) + ch * 16 : 0x80000000u;
+    v_loff = 2 * KBYTES + row * (2 * D) + (((ch >> 2) ^ vx<D>(row)) << 6) + ((ch & 3) << 4);
+  }
+  const unsigned k_gstep = ESZ * KROWS * (unsigned)p.ks;                  // bytes between a thread's K chunks
+  const unsigned v_gstep = FP8 ? 4096u : 2u * VROWS * (unsigned)p.vs;
+  constexpr int K_LSTEP = KROWS * RB, V_LSTEP = FP8 ? 4096 : VROWS * 2 * D;
+  // ---- staging registers ----------------------------------------------------------------------------
+  u32x4 kreg[KCH], vreg[VCH];
+  auto load_tile = [&](int j) {  // rows / tiles past the end are outside the descriptor and read as zeros
+    const int64_t ko = (int64_t)j * k_tile_stride, vo = (int64_t)j * v_tile_stride;
+    const __amdgpu_buffer_rsrc_t k_rs = make_rsrc(kbase + ko, (unsigned)max((int64_t)0, k_bytes - ko));
+    const __amdgpu_buffer_rsrc_t v_rs = make_rsrc(vbase + vo, (unsigned)max((int64_t)0, v_bytes - vo));
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) kreg[i] = buf_load16(k_rs, k_goff, i * k_gstep);
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) vreg[i] = buf_load16(v_rs, v_goff, i * v_gstep);
+  };
+  auto store_tile = [&](auto buf_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+      u32x4 val = kreg[i];
+      *reinterpret_cast<u32x4*>(smem + k_loff + i * K_LSTEP + BUF * KBYTES) = val;
+    }
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) {
+      u32x4 val = vreg[i];
+      if constexpr (VT == LBFA_BF16) val = bf16x8_to_f16x8(val);  // bf16 -> fp16 on the way in (src/core.py:307-308 `v.to(float16)`)
+      *reinterpret_cast<u32x4*>(smem + v_loff + i * V_LSTEP + BUF * VBYTES) = val;
+    }
+  };
+
+  load_tile(0);  // first K / V tile: in flight while Q is fetched (and quantised)
+
   // ---- Q fragments (B operand of the score MFMA): lane (r, hh) holds bytes [32s+16hh, +16) of its row.
   // Rows >= Sq are out of the descriptor's range and read as zeros.
   i32x4 qf[KS];
@@ -234,29 +285,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   int n_tiles = nK;
   if constexpr (CAUSAL) n_tiles = min(nK, 2 * (qt + 1));
 
-  // ---- loop-invariant per-thread offsets: global (voffset) and LDS -----------------------------------
-  // Chunk i of a thread is chunk 0 moved down by a whole number of rows (KROWS / VROWS per pass), which leaves the
-  // swizzles unchanged: one voffset / LDS offset per operand, the rest is a scalar soffset and a ds immediate.
-  constexpr int KCPR = RB / 16, KROWS = 256 / KCPR;              // K: 16-B chunks per row, rows per pass
-  constexpr int VCPR = FP8 ? 1 : D / 8, VROWS = FP8 ? 0 : 256 / VCPR;
-  unsigned k_goff, k_loff, v_goff, v_loff;
-  {
-    const int row = t / KCPR, ch = t % KCPR;
-    // padded channels: an offset beyond any window -> the range check returns zeros (windows are < 2 GiB, checked by the C ABI)
-    k_goff = ch * 16 < ESZ * dq_valid ? ESZ * (unsigned)row * (unsigned)p.ks + ch * 16 : 0x80000000u;
-    k_loff = row * RB + ((ch ^ kx<RB>(row)) << 4);
-  }
-  if constexpr (FP8) {
-    v_goff = t * 16;
-    v_loff = 2 * KBYTES + t * 16;
-  } else {
-    const int row = t / VCPR, ch = t % VCPR;
-    v_goff = ch * 8 < p.d_valid ? 2 * ((unsigned)row * (unsigned)p.vs) + ch * 16 : 0x80000000u;
-    v_loff = 2 * KBYTES + row * (2 * D) + (((ch >> 2) ^ vx<D>(row)) << 6) + ((ch & 3) << 4);
-  }
-  const unsigned k_gstep = ESZ * KROWS * (unsigned)p.ks;                  // bytes between a thread's K chunks
-  const unsigned v_gstep = FP8 ? 4096u : 2u * VROWS * (unsigned)p.vs;
-  constexpr int K_LSTEP = KROWS * RB, V_LSTEP = FP8 ? 4096 : VROWS * 2 * D;
   // Fragment read addresses.  The swizzles depend only on the low row bits, so the block / k-step / high-half /
   // buffer parts are compile-time byte offsets folded into the ds_read immediates; per lane only KS (K) and
   // DB or 4 (V) base registers are needed.
@@ -282,32 +310,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       vf_base[i] = 2 * KBYTES + vrow * (2 * D) + ((i ^ vx<D>(vrow)) << 6) + vcol;
     }
   }
-
-  // ---- staging registers ----------------------------------------------------------------------------
-  u32x4 kreg[KCH], vreg[VCH];
-  auto load_tile = [&](int j) {  // rows / tiles past the end are outside the descriptor and read as zeros
-    const int64_t ko = (int64_t)j * k_tile_stride, vo = (int64_t)j * v_tile_stride;
-    const __amdgpu_buffer_rsrc_t k_rs = make_rsrc(kbase + ko, (unsigned)max((int64_t)0, k_bytes - ko));
-    const __amdgpu_buffer_rsrc_t v_rs = make_rsrc(vbase + vo, (unsigned)max((int64_t)0, v_bytes - vo));
-#pragma unroll
-    for (int i = 0; i < KCH; ++i) kreg[i] = buf_load16(k_rs, k_goff, i * k_gstep);
-#pragma unroll
-    for (int i = 0; i < VCH; ++i) vreg[i] = buf_load16(v_rs, v_goff, i * v_gstep);
-  };
-  auto store_tile = [&](auto buf_tag) {
-    constexpr int BUF = decltype(buf_tag)::value;
-#pragma unroll
-    for (int i = 0; i < KCH; ++i) {
-      u32x4 val = kreg[i];
-      *reinterpret_cast<u32x4*>(smem + k_loff + i * K_LSTEP + BUF * KBYTES) = val;
-    }
-#pragma unroll
-    for (int i = 0; i < VCH; ++i) {
-      u32x4 val = vreg[i];
-      if constexpr (VT == LBFA_BF16) val = bf16x8_to_f16x8(val);  // bf16 -> fp16 on the way in (src/core.py:307-308 `v.to(float16)`)
-      *reinterpret_cast<u32x4*>(smem + v_loff + i * V_LSTEP + BUF * VBYTES) = val;
-    }
-  };
 
   // ---- running state --------------------------------------------------------------------------------
   f32x16 acc_o[DB];
@@ -557,7 +559,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     __syncthreads();  // measured: dropping every per-tile barrier (wrong results, timing only) gains 0.8 % at D=64, 3.8 % at D=128
   };
 
-  load_tile(0);
   store_tile(B0{});
   __syncthreads();
   int j = 0;

@@ -9,10 +9,6 @@ from ._tensor import ops_for
 from .quant import Fp8V
 from .quant_per_block import _bhs
 
-# Optional profiling hook: callable(start_event, stop_event) given two recorded events that bracket the fused
-# attention launch on its stream (bench.py uses it to time the dominant kernel inside the timed region).
-EVENT_HOOK = None
-
 
 def forward(q, k, v, q_scale, k_scale, tensor_layout="HND", output_dtype=None, return_lse=False,
             is_causal=False, v_scale=None):
@@ -47,19 +43,12 @@ def forward(q, k, v, q_scale, k_scale, tensor_layout="HND", output_dtype=None, r
         (_, _, _), v3s = _bhs(ops.shape(v), ops.strides(v), tensor_layout)
         v_ptr, v3 = ops.ptr(v), _lib.strides3(v3s)
     lse = ops.empty((B, Hq, Sq), ops.float32, q) if return_lse else ops.empty((0,), ops.float32, q)
-    hook = EVENT_HOOK
-    if hook is not None:
-        ev0, ev1 = ops.torch.cuda.Event(enable_timing=True), ops.torch.cuda.Event(enable_timing=True)
-        ev0.record()
     with ops.device_guard(q):
         _lib.check(lib.lbfa_attn_fwd(ops.ptr(q), ops.ptr(k), v_ptr, v_code, ops.ptr(o), o_code,
                                      ops.ptr(lse) if return_lse else None, ops.ptr(q_scale), ops.ptr(k_scale),
                                      ops.ptr(v_scale) if v_scale is not None else None,
                                      B, Hq, Hkv, Sq, Sk, D, _lib.strides3(q3), _lib.strides3(k3), v3,
                                      _lib.strides3(o3), 1 if is_causal else 0, ops.stream(q)), lib)
-    if hook is not None:
-        ev1.record()
-        hook(ev0, ev1)
     return o, lse
 
 

@@ -184,7 +184,7 @@ def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_
     cu_seqlens int32 / int64 [B+1] on the device.  As in the reference, smooth-K subtracts ONE mean taken over all
     packed tokens (`k.mean(dim=0)`, :452-454), quantisation blocks restart at every sequence, and each sequence
     attends only to itself (causal: len_q == len_k per sequence).  The whole batch runs in one `lbfa_forward_varlen`
-    call - 5 launches whatever the number of sequences, no host read of cu_seqlens."""
+    call - 4 launches whatever the number of sequences, no host read of cu_seqlens."""
     ops, dtype = _check_inputs(q, k, v)
     qshape = ops.shape(q)
     if len(qshape) != 3:

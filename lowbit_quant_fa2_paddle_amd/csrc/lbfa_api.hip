@@ -413,6 +413,7 @@ int lbfa_sdpa_fwd(const void* q, const void* k, const void* v, int dtype, void* 
   if (Hq % Hkv != 0) return fail(LBFA_EINVAL, "num_qo_heads (%d) must be divisible by num_kv_heads (%d)", Hq, Hkv);
   if (dtype != LBFA_F16 && dtype != LBFA_BF16) return fail(LBFA_EINVAL, "Input tensors must be in dtype of float16 or bfloat16");
   if (is_causal && Sq != Sk) return fail(LBFA_EINVAL, "qo_len and kv_len must be equal for causal attention");
+  if (!(sm_scale > 0.f)) return fail(LBFA_EINVAL, "lbfa_sdpa_fwd: sm_scale must be positive (the row maximum is tracked on the unscaled scores)");
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (reinterpret_cast<uintptr_t>(o) & 7u))
     return fail(LBFA_EINVAL, "lbfa_sdpa_fwd: q/k/v must be 16-byte aligned and o 8-byte aligned");
   if ((strides_q[0] | strides_q[1] | strides_q[2] | strides_k[0] | strides_k[1] | strides_k[2] | strides_v[0] | strides_v[1] | strides_v[2]) % 8 != 0)

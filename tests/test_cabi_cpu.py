@@ -106,6 +106,8 @@ def test_one_call_and_varlen_validation(lib):
     assert st == _lib.LBFA_EINVAL and b"qo_len and kv_len must be equal" in lib.lbfa_last_error()
     st = lib.lbfa_sdpa_fwd(p, p, p, 2, p, None, 1, 2, 2, 8, 8, 64, s3, s3, s3, s3, 0.125, 0, None)
     assert st == _lib.LBFA_EINVAL and b"float16 or bfloat16" in lib.lbfa_last_error()
+    st = lib.lbfa_sdpa_fwd(p, p, p, 0, p, None, 1, 2, 2, 8, 8, 64, s3, s3, s3, s3, -0.125, 0, None)
+    assert st == _lib.LBFA_EINVAL and b"sm_scale must be positive" in lib.lbfa_last_error()
 
 
 def test_api_surface_matches_reference():

@@ -455,3 +455,29 @@ def test_c_abi_without_any_framework(dev):
                    check=True, capture_output=True, timeout=600)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("pv", ["fp16", "fp8", "unquantised"])
+def test_packed_qkv_views_are_consumed_in_place(oracle, dev, pv):
+    """q, k, v as strided views of one packed [B, S, 3, H, D] projection output (NHD, sequence stride 3*H*D): layouts are
+    handed to the C ABI as strides (attn_qk_int8_per_block.py:183-196), no contiguous copies are made."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    B, S, H, D = 2, 200, 4, 64
+    q, k, v = oracle.make_inputs(B, H, S, D, seed=23, layout="NHD", k_bias=0.2)
+    qkv = torch.stack([_t(a, "fp16", dev) for a in (q, k, v)], dim=2)  # [B, S, 3, H, D]
+    tq, tk, tv = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    assert not tq.is_contiguous() and tq.stride(1) == 3 * H * D
+    if pv == "unquantised":
+        o = lb.core.flash_attn_fp16(tq, tk, tv, tensor_layout="NHD", is_causal=True)
+        ref = np.transpose(oracle.sdpa_naive(*(np.transpose(a, (0, 2, 1, 3)).astype(np.float64) for a in (q, k, v)), is_causal=True), (0, 2, 1, 3))
+        _o_close(_np(o), ref, "fp16")
+        return
+    fn = lb.lowbit_fa_qk_int8_pv_fp16_triton if pv == "fp16" else lb.lowbit_fa_qk_int8_pv_fp8_cuda
+    o = fn(tq, tk, tv, tensor_layout="NHD", is_causal=True)
+    o_c = fn(tq.contiguous(), tk.contiguous(), tv.contiguous(), tensor_layout="NHD", is_causal=True)
+    assert torch.equal(o, o_c)
+    # and the packed-batch operator on the flattened token axis of the same views
+    cu = torch.arange(0, (B + 1) * S, S, dtype=torch.int32, device=dev)
+    flat = qkv.reshape(B * S, 3, H, D)
+    ov = lb.lowbit_fa_varlen(flat[:, 0], flat[:, 1], flat[:, 2], cu, cu, S, S, is_causal=True)
+    assert tuple(ov.shape) == (B * S, H, D) and torch.isfinite(ov).all()

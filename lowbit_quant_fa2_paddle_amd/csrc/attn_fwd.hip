@@ -169,10 +169,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   constexpr int K_LSTEP = KROWS * RB, V_LSTEP = FP8 ? 4096 : VROWS * 2 * D;
   // ---- staging registers ----------------------------------------------------------------------------
   u32x4 kreg[KCH], vreg[VCH];
+  // windows are < 2 GiB (checked by the C ABI): remaining bytes in 32-bit scalar arithmetic (the lookahead tile past the
+  // end gets a window of 0 bytes)
+  const int k_bytes32 = (int)k_bytes, v_bytes32 = (int)v_bytes, k_stride32 = (int)k_tile_stride, v_stride32 = (int)v_tile_stride;
   auto load_tile = [&](int j) {  // rows / tiles past the end are outside the descriptor and read as zeros
-    const int64_t ko = (int64_t)j * k_tile_stride, vo = (int64_t)j * v_tile_stride;
-    const __amdgpu_buffer_rsrc_t k_rs = make_rsrc(kbase + ko, (unsigned)max((int64_t)0, k_bytes - ko));
-    const __amdgpu_buffer_rsrc_t v_rs = make_rsrc(vbase + vo, (unsigned)max((int64_t)0, v_bytes - vo));
+    const int ko = j * k_stride32, vo = j * v_stride32;
+    const int k_rem = j < nK ? max(0, k_bytes32 - ko) : 0, v_rem = j < nK ? max(0, v_bytes32 - vo) : 0;
+    const __amdgpu_buffer_rsrc_t k_rs = make_rsrc(kbase + (j < nK ? ko : 0), (unsigned)k_rem);
+    const __amdgpu_buffer_rsrc_t v_rs = make_rsrc(vbase + (j < nK ? vo : 0), (unsigned)v_rem);
 #pragma unroll
     for (int i = 0; i < KCH; ++i) kreg[i] = buf_load16(k_rs, k_goff, i * k_gstep);
 #pragma unroll
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc_o[db][i] = 0.f;
   float m_run = -INFINITY;  // reference max (base-2 domain), identical in both halves of a row
-  float l_run = 0.f;        // running row sum over all keys seen so far (identical in both halves of a row)
+  float l_run = 0.f;        // running row sum over the keys THIS lane has seen (its half of every tile); halves are added in the epilogue
 
   // The int8 MFMA accumulates on top of this constant block (kept in registers for the whole kernel).
   i32x16 cmagic;
@@ -344,6 +348,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   const float G = __builtin_ldexpf(1.0f, gexp), invG = __builtin_ldexpf(1.0f, -gexp);
   const float g = __builtin_ldexpf(1.0f, gexp - 22), invg = __builtin_ldexpf(1.0f, 22 - gexp);
   auto grid_up = [&](float m) { return __builtin_ceilf(m * invG) * G; };  // -inf stays -inf
+  // Per-tile constants sc (dequantisation scale on the g grid) and c0 = -kMagic * sc are the same for every lane: lane l
+  // of the wave computes them for tile 64 c + l once per chunk of 64 tiles, and each tile fetches its pair with two
+  // v_readlane (no per-tile global load, no per-tile float math on uniform values).
+  float sc_tab = 0.f, c0_tab = 0.f;
+  auto refresh_scale_table = [&](int j0) {
+    if constexpr (!QK16) {
+      const int jt = j0 + lane;
+      const float ks_l = jt < nK ? ksc[jt * ksc_blk] : 0.f;
+      sc_tab = __builtin_rintf(qsc * ks_l * invg) * g;
+      c0_tab = -kMagic * sc_tab;  // exact
+    }
+  };
+  refresh_scale_table(0);
 
   constexpr float kPLimit = 32768.0f;  // fp16 P must stay finite (max 65504)
 
@@ -359,8 +376,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       sc = p.qk_scale;  // fp32 scores: one fma per element, no bias to fold
       c0 = 0.f;
     } else {
-      sc = __builtin_rintf(qsc * ksc[j * ksc_blk] * invg) * g;  // per-tile dequant scale on the g grid
-      c0 = -kMagic * sc;                                        // exact
+      sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc_tab), j & 63));
+      c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c0_tab), j & 63));
     }
     float x[2][16];  // scores as floats kMagic + s (accumulator bits), then overwritten in place by P
     // -- S^T = K Q^T (int8 -> int32, biased by kMagic): two 32-key blocks
@@ -427,7 +444,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
           for (int i = 0; i < 16; ++i) acc_o[db][i] *= alpha;
       }
     };
-    // Row sums.  l_run always holds the sum over ALL 64 keys of the row (both lane halves).
+    // Row sums.  l_run holds this lane's half of the row (32 of every 64 keys): both halves of a row share m_run, hence
+    // every rescale factor, so the halves can be combined once, in the epilogue.
     //  * ONES path (lazy fp16 tiles when the matrix pipe has slack, i.e. D = 64): the sum comes from four extra
     //    MFMAs with an all-ones A operand, O_l^T = 1 P^T - every accumulator row is the column sum of P^T, over
     //    both halves - instead of 32 v_add_f32 per lane on the saturated VALU;
@@ -506,8 +524,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       update_reference(THR);
       exponentiate();
     }
-    if constexpr (ONES) l_run += tile_sum;
-    else l_run += half_swap_sum(tile_sum);
+    if constexpr (ONES) l_run += 0.5f * tile_sum;  // the MFMA row sum already covers both halves
+    else l_run += tile_sum;
 
     // -- O^T += V^T P^T : P^T fragments straight from the score accumulators
     if constexpr (PRIO & 2) __builtin_amdgcn_s_setprio(1);
@@ -551,6 +569,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
   auto step = [&](auto buf_tag, auto nbuf_tag, int j, auto masked_tag) {
+    if ((j & 63) == 0 && j != 0) refresh_scale_table(j);  // wave-uniform, once per 64 tiles
     load_tile(j + 1);
     bool skip = false;
     if constexpr (decltype(masked_tag)::value && CAUSAL) skip = j * 64 > row0 + 31;  // all keys above all rows of this wave
@@ -577,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   }
 
   // ---- epilogue: O = O^T / l (x v_scale), LSE ------------------------------------------------------------
-  const float l_tot = l_run;  // already the sum over both lane halves
+  const float l_tot = half_swap_sum(l_run);
   const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;  // a sequence without keys (packed batches only) yields zeros
   if (qrow < Sq) {
     unsigned short* op = reinterpret_cast<unsigned short*>(p.o) + o_off + (int64_t)h * p.oh + (int64_t)qrow * p.os;

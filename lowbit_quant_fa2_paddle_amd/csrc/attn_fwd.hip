@@ -219,16 +219,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       for (int hf = 0; hf < 2; ++hf) {
         const int col = 32 * s + 16 * hh + 8 * hf;
         const u32x4 raw = buf_load16(q_rs, col < p.d_valid ? 2 * ((unsigned)qrow * (unsigned)p.qs + col) : 0x80000000u, 0);
-        u32x4 vraw = u32x4{0, 0, 0, 0};
-        if (vec != nullptr) vraw = *reinterpret_cast<const u32x4*>(vec + col);
+        float xv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float xv = load_cvt<OT>((unsigned short)((e & 1) ? (raw[e >> 1] >> 16) : (raw[e >> 1] & 0xffffu)));
-          const float kv = load_cvt<OT>((unsigned short)((e & 1) ? (vraw[e >> 1] >> 16) : (vraw[e >> 1] & 0xffffu)));
-          dot += xv * kv;
-          const float x = xv * p.q_sm_scale;
+          xv[e] = load_cvt<OT>((unsigned short)((e & 1) ? (raw[e >> 1] >> 16) : (raw[e >> 1] & 0xffffu)));
+          const float x = xv[e] * p.q_sm_scale;
           xs[s][8 * hf + e] = x;
           amax = fmaxf(amax, fabsf(x));
+        }
+        if (vec != nullptr) {  // wave-uniform: only when the caller wants the LSE with smooth-K
+          const u32x4 vraw = *reinterpret_cast<const u32x4*>(vec + col);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            dot += xv[e] * load_cvt<OT>((unsigned short)((e & 1) ? (vraw[e >> 1] >> 16) : (vraw[e >> 1] & 0xffffu)));
         }
       }
     row_corr = load_cvt<OT>(store_cvt<OT>(half_swap_sum(dot)));  // rounded to the storage dtype (src/core.py:294-304)

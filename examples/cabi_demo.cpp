@@ -44,7 +44,7 @@ int main() {
   CK(hipStreamCreate(&stream));
   const int64_t sq[3] = {(int64_t)Hq * S * D, (int64_t)S * D, D};   // HND: {batch, head, seq} element strides
   const int64_t sk[3] = {(int64_t)Hkv * S * D, (int64_t)S * D, D};
-  const float sm_scale = 1.0f / std::sqrt((float)D);
+  const double sm_scale = 1.0 / std::sqrt((double)D);  // a double, as the reference's Python float
   int st = lbfa_forward(dq, dk, dv, LBFA_F16, dout, dlse, dws, ws_bytes, B, Hq, Hkv, S, S, D, sq, sk, sk, sq, sm_scale, 127, 127,
                         /*pv_fp8=*/0, causal, /*smooth_k=*/1, stream);
   if (st != LBFA_OK) { fprintf(stderr, "lbfa_forward failed (%d): %s\n", st, lbfa_last_error()); return 1; }
@@ -65,7 +65,7 @@ int main() {
       for (int j = 0; j < lim; ++j) {
         float acc = 0;
         for (int d = 0; d < D; ++d) acc += qf[((size_t)h * S + i) * D + d] * kf[((size_t)hk * S + j) * D + d];
-        p[j] = acc * sm_scale;
+        p[j] = acc * (float)sm_scale;
         mx = std::fmax(mx, p[j]);
       }
       double l = 0;

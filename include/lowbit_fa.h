@@ -146,7 +146,10 @@ int lbfa_profile_next_attn(void* start_event, void* stop_event);
  *             (lse2 / 1.44269504 + (q . km) * sm_scale, src/core.py:344-350).
  *   workspace: >= lbfa_forward_workspace_bytes(...) bytes, 16-byte aligned, caller-owned scratch (int8 codes,
  *             scales, km, partial sums, fp8 V); contents are undefined afterwards.
- *   sm_scale: softmax scale (1/sqrt(original head_dim) by default on the host side); q_qmax/k_qmax in {127, 7}.
+ *   sm_scale: softmax scale (1/sqrt(original head_dim) by default on the host side), a double as in the reference's
+ *             Python: the Q quantiser multiplies by fp32(sm_scale * 1.44269504) formed in double
+ *             (src/triton/quant_per_block.py:226) - with 4-bit-range codes a 1-ulp difference there flips codes;
+ *             q_qmax/k_qmax in {127, 7}.
  *   D       : head dim of q, k, v, o - 64, 128, or ANY multiple of 8 up to 128: the kernels then work on 64 / 128
  *             channels and treat the missing ones as the zero padding of src/core.py:277-287 (never read, never
  *             written), so the host makes no padded copies; results are bit-identical to padding on the host.
@@ -156,7 +159,7 @@ size_t lbfa_forward_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int 
 int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o, float* lse, void* workspace,
                  size_t workspace_bytes, int B, int Hq, int Hkv, int Sq, int Sk, int D,
                  const int64_t strides_q[3], const int64_t strides_k[3], const int64_t strides_v[3],
-                 const int64_t strides_o[3], float sm_scale, int q_qmax, int k_qmax, int pv_fp8, int is_causal,
+                 const int64_t strides_o[3], double sm_scale, int q_qmax, int k_qmax, int pv_fp8, int is_causal,
                  int smooth_k, void* stream);
 
 /*
@@ -170,7 +173,7 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
 int lbfa_sdpa_fwd(const void* q, const void* k, const void* v, int dtype, void* o, float* lse,
                   int B, int Hq, int Hkv, int Sq, int Sk, int D,
                   const int64_t strides_q[3], const int64_t strides_k[3], const int64_t strides_v[3],
-                  const int64_t strides_o[3], float sm_scale, int is_causal, void* stream);
+                  const int64_t strides_o[3], double sm_scale, int is_causal, void* stream);
 
 /*
  * Packed variable-length batches (reference: `sageattn_varlen`, src/core.py:356-491).
@@ -208,7 +211,7 @@ int lbfa_forward_varlen(const void* q, const void* k, const void* v, int dtype, 
                         const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, void* workspace, size_t workspace_bytes,
                         int B, int Hq, int Hkv, int total_q, int total_k, int max_seqlen_q, int max_seqlen_k, int D,
                         const int64_t strides_q[2], const int64_t strides_k[2], const int64_t strides_v[2],
-                        const int64_t strides_o[2], float sm_scale, int q_qmax, int k_qmax, int is_causal, int smooth_k,
+                        const int64_t strides_o[2], double sm_scale, int q_qmax, int k_qmax, int is_causal, int smooth_k,
                         void* stream);
 
 #ifdef __cplusplus

@@ -21,6 +21,7 @@ BLKQ, BLKK = 128, 64
 _i64x3 = ctypes.c_int64 * 3
 _i64x2 = ctypes.c_int64 * 2
 _vp, _ci, _cf, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_cd = ctypes.c_double
 
 # name -> (restype, argtypes); must list every symbol declared in include/lowbit_fa.h
 SIGNATURES = {
@@ -41,10 +42,10 @@ SIGNATURES = {
     "lbfa_forward": (_ci, [_vp, _vp, _vp, _ci, _vp, _vp, _vp, _sz, _ci, _ci, _ci, _ci, _ci, _ci,
                            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
-                           _cf, _ci, _ci, _ci, _ci, _ci, _vp]),
+                           _cd, _ci, _ci, _ci, _ci, _ci, _vp]),
     "lbfa_sdpa_fwd": (_ci, [_vp, _vp, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci,
                             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
-                            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), _cf, _ci, _vp]),
+                            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), _cd, _ci, _vp]),
     "lbfa_quant_per_block_varlen": (_ci, [_vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _cf, _ci, _ci, _ci, _ci, _ci, _ci,
                                           ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), _vp]),
     "lbfa_attn_fwd_varlen": (_ci, [_vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -56,7 +57,7 @@ SIGNATURES = {
                                   _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci,
                                   ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                   ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
-                                  _cf, _ci, _ci, _ci, _ci, _vp]),
+                                  _cd, _ci, _ci, _ci, _ci, _vp]),
 }
 
 _lock = threading.Lock()

@@ -322,7 +322,7 @@ size_t lbfa_forward_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int 
 int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o, float* lse, void* workspace,
                  size_t workspace_bytes, int B, int Hq, int Hkv, int Sq, int Sk, int D,
                  const int64_t strides_q[3], const int64_t strides_k[3], const int64_t strides_v[3],
-                 const int64_t strides_o[3], float sm_scale, int q_qmax, int k_qmax, int pv_fp8, int is_causal,
+                 const int64_t strides_o[3], double sm_scale, int q_qmax, int k_qmax, int pv_fp8, int is_causal,
                  int smooth_k, void* stream) {
   const int Dg = D;  // head dim of the caller's tensors
   if (!q || !k || !v || !o || !workspace || !strides_q || !strides_k || !strides_v || !strides_o)
@@ -388,10 +388,10 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
   p.group = Hq / Hkv;
   p.lse_corr = nullptr;
   p.lse_scale = 1.0f / 1.44269504f;   // natural-log LSE (src/core.py:347)
-  p.lse_corr_scale = sm_scale;
+  p.lse_corr_scale = (float)sm_scale;
   dense_scale_layout(p);
   p.d_valid = Dg;
-  p.q_sm_scale = sm_scale * 1.44269504f;
+  p.q_sm_scale = (float)(sm_scale * 1.44269504);  // ONE rounding of the double product, as the reference's kernel argument
   p.q_qmax = (float)q_qmax;
   p.q_dot_vec = want_corr ? (const unsigned short*)km : nullptr;
   if ((int64_t)B * Hq * p.nQ > 0x7fffffffLL) return fail(LBFA_EINVAL, "lbfa_forward: grid too large");
@@ -406,14 +406,14 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
 int lbfa_sdpa_fwd(const void* q, const void* k, const void* v, int dtype, void* o, float* lse,
                   int B, int Hq, int Hkv, int Sq, int Sk, int D,
                   const int64_t strides_q[3], const int64_t strides_k[3], const int64_t strides_v[3],
-                  const int64_t strides_o[3], float sm_scale, int is_causal, void* stream) {
+                  const int64_t strides_o[3], double sm_scale, int is_causal, void* stream) {
   if (!q || !k || !v || !o || !strides_q || !strides_k || !strides_v || !strides_o) return fail(LBFA_EINVAL, "lbfa_sdpa_fwd: null pointer");
   if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Sk <= 0) return fail(LBFA_EINVAL, "lbfa_sdpa_fwd: empty tensor");
   if (!head_dim_ok(D)) return fail(LBFA_EINVAL, "Unsupported head_dim: %d", D);
   if (Hq % Hkv != 0) return fail(LBFA_EINVAL, "num_qo_heads (%d) must be divisible by num_kv_heads (%d)", Hq, Hkv);
   if (dtype != LBFA_F16 && dtype != LBFA_BF16) return fail(LBFA_EINVAL, "Input tensors must be in dtype of float16 or bfloat16");
   if (is_causal && Sq != Sk) return fail(LBFA_EINVAL, "qo_len and kv_len must be equal for causal attention");
-  if (!(sm_scale > 0.f)) return fail(LBFA_EINVAL, "lbfa_sdpa_fwd: sm_scale must be positive (the row maximum is tracked on the unscaled scores)");
+  if (!(sm_scale > 0.0)) return fail(LBFA_EINVAL, "lbfa_sdpa_fwd: sm_scale must be positive (the row maximum is tracked on the unscaled scores)");
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (reinterpret_cast<uintptr_t>(o) & 7u))
     return fail(LBFA_EINVAL, "lbfa_sdpa_fwd: q/k/v must be 16-byte aligned and o 8-byte aligned");
   if ((strides_q[0] | strides_q[1] | strides_q[2] | strides_k[0] | strides_k[1] | strides_k[2] | strides_v[0] | strides_v[1] | strides_v[2]) % 8 != 0)
@@ -441,7 +441,7 @@ int lbfa_sdpa_fwd(const void* q, const void* k, const void* v, int dtype, void* 
   p.lse_corr_scale = 0.0f;
   dense_scale_layout(p);
   p.d_valid = D;
-  p.qk_scale = sm_scale * 1.44269504f;
+  p.qk_scale = (float)(sm_scale * 1.44269504);
   if ((int64_t)B * Hq * p.nQ > 0x7fffffffLL) return fail(LBFA_EINVAL, "lbfa_sdpa_fwd: grid too large");
   g_err[0] = 0;
   const hipEvent_t e0 = g_prof_start, e1 = g_prof_stop;
@@ -547,7 +547,7 @@ int lbfa_forward_varlen(const void* q, const void* k, const void* v, int dtype, 
                         const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, void* workspace, size_t workspace_bytes,
                         int B, int Hq, int Hkv, int total_q, int total_k, int max_seqlen_q, int max_seqlen_k, int D,
                         const int64_t strides_q[2], const int64_t strides_k[2], const int64_t strides_v[2],
-                        const int64_t strides_o[2], float sm_scale, int q_qmax, int k_qmax, int is_causal, int smooth_k,
+                        const int64_t strides_o[2], double sm_scale, int q_qmax, int k_qmax, int is_causal, int smooth_k,
                         void* stream) {
   const int Dg = D;  // head dim of the caller's tensors
   if (!q || !k || !v || !o || !workspace || !cu_seqlens_q || !cu_seqlens_k || !strides_q || !strides_k || !strides_v || !strides_o)
@@ -578,7 +578,7 @@ int lbfa_forward_varlen(const void* q, const void* k, const void* v, int dtype, 
   if (st) return st;
   return attn_varlen_core("lbfa_forward_varlen", (const int8_t*)q, k8, v, dtype, o, dtype, nullptr, ks, cu_seqlens_q, cu_seqlens_k,
                           nullptr, nullptr, B, Hq, Hkv, max_seqlen_q, max_seqlen_k, D, Dg, strides_q, sk8, strides_v, strides_o,
-                          is_causal, stream, true, sm_scale * 1.44269504f, q_qmax);
+                          is_causal, stream, true, (float)(sm_scale * 1.44269504), q_qmax);
 }
 
 }  // extern "C"

@@ -1,0 +1,80 @@
+"""Seeded fuzz of the public operators against the CPU oracle: random small shapes (ragged lengths, GQA, head dims,
+layouts, dtypes, causal, return_lse, int8 / int4-range / fp8-PV / un-quantised, packed batches).  Catches shape-dependent
+code paths (odd tile counts, single-tile sequences, masked instances ...) that hand-picked cases miss."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import TDT, _canon, _np, _o_close, _t, dev  # noqa: F401
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _rand_cfg(rng):
+    D = int(rng.choice([64, 128, 32, 80, 96, 40]))
+    Hkv = int(rng.choice([1, 2, 3]))
+    H = Hkv * int(rng.choice([1, 2, 4]))
+    causal = bool(rng.integers(0, 2))
+    Sq = int(rng.choice([1, 17, 64, 65, 127, 128, 129, 191, 192, 200, 256, 300, 320, 383, 448, 513]))
+    Sk = Sq if causal or rng.integers(0, 2) else int(rng.choice([1, 33, 64, 100, 192, 257, 320, 450]))
+    return dict(B=int(rng.integers(1, 3)), H=H, Hkv=Hkv, Sq=Sq, Sk=Sk, D=D, causal=causal,
+                layout=str(rng.choice(["HND", "NHD"])), dtype=str(rng.choice(["fp16", "bf16"])),
+                lse=bool(rng.integers(0, 2)), smooth=bool(rng.integers(0, 4)), bias=float(rng.choice([0.0, 0.3, -0.5])))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_low_bit_operators(oracle, dev, seed):
+    import lowbit_quant_fa2_paddle_amd as lb
+    rng = np.random.default_rng(1000 + seed)
+    c = _rand_cfg(rng)
+    kind = ["int8", "int8", "int4", "q8k4", "fp8"][seed % 5]
+    q, k, v = oracle.make_inputs(c["B"], c["H"], c["Sq"], c["D"], seed=seed, layout=c["layout"], dtype=c["dtype"], Hkv=c["Hkv"],
+                                 Sk=c["Sk"], k_bias=c["bias"])
+    tq, tk, tv = (_t(a, c["dtype"], dev) for a in (q, k, v))
+    kw = dict(tensor_layout=c["layout"], is_causal=c["causal"], smooth_k=c["smooth"], return_lse=c["lse"])
+    okw = dict(dtype=c["dtype"], tensor_layout=c["layout"], is_causal=c["causal"], smooth_k=c["smooth"], return_lse=c["lse"],
+               tail="neg_inf", amax_floor=1e-7)
+    if kind == "int8":
+        out, ref = lb.lowbit_fa_qk_int8_pv_fp16_triton(tq, tk, tv, **kw), oracle.lowbit_fa_forward(q, k, v, **okw)
+    elif kind == "int4":
+        out, ref = lb.lowbit_fa_qk_int4_pv_fp16_triton(tq, tk, tv, **kw), oracle.lowbit_fa_forward(q, k, v, q_qmax=7, k_qmax=7, **okw)
+    elif kind == "q8k4":
+        out, ref = lb.lowbit_fa_qk_int4_pv_fp16_triton(tq, tk, tv, q_bits=8, **kw), oracle.lowbit_fa_forward(q, k, v, k_qmax=7, **okw)
+    else:
+        okw.pop("tail")
+        out, ref = lb.lowbit_fa_qk_int8_pv_fp8_cuda(tq, tk, tv, **kw), oracle.lowbit_fa_forward(q, k, v, pv="fp8", **okw)
+    o, o_ref = (out[0], ref[0]) if c["lse"] else (out, ref)
+    assert tuple(o.shape) == q.shape, c
+    if kind == "fp8":
+        _o_close(_np(o), o_ref, c["dtype"], atol=3e-2, rtol=3e-2)  # e4m3 P codes flip on 1-ulp exp2 differences (parity unpinned)
+    else:
+        _o_close(_np(o), o_ref, c["dtype"])
+    if c["lse"]:
+        tol = 2e-3 + (2.0 ** -9 * np.abs(ref[1]).max() if kind == "fp8" or c["dtype"] == "bf16" else 0.0)
+        assert np.abs(_np(out[1]) - ref[1]).max() <= tol, c
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_unquantised_and_varlen(oracle, dev, seed):
+    import lowbit_quant_fa2_paddle_amd as lb
+    rng = np.random.default_rng(2000 + seed)
+    c = _rand_cfg(rng)
+    if seed % 2 == 0:  # un-quantised kernel vs fp64 SDPA
+        q, k, v = oracle.make_inputs(c["B"], c["H"], c["Sq"], c["D"], seed=seed, layout=c["layout"], dtype=c["dtype"], Hkv=c["Hkv"],
+                                     Sk=c["Sk"], k_bias=c["bias"])
+        tq, tk, tv = (_t(a, c["dtype"], dev) for a in (q, k, v))
+        o = lb.core.flash_attn_fp16(tq, tk, tv, tensor_layout=c["layout"], is_causal=c["causal"])
+        ref = oracle.sdpa_naive(*(_canon(a, c["layout"]).astype(np.float64) for a in (q, k, v)), is_causal=c["causal"],
+                                sm_scale=c["D"] ** -0.5)
+        _o_close(_canon(_np(o), c["layout"]), ref, c["dtype"])
+    else:  # packed batch vs the varlen oracle
+        n = int(rng.integers(1, 5))
+        lens_q = [int(x) for x in rng.choice([1, 5, 64, 100, 128, 129, 250, 320], size=n)]
+        lens_k = lens_q if c["causal"] else [int(x) for x in rng.choice([1, 40, 64, 65, 192, 300], size=n)]
+        q, k, v, cu_q, cu_k = oracle.make_varlen_inputs(lens_q, lens_k, c["H"], c["Hkv"], c["D"], seed=seed, dtype=c["dtype"], k_bias=c["bias"])
+        tq, tk, tv = (_t(a, c["dtype"], dev) for a in (q, k, v))
+        o = lb.sageattn_varlen(tq, tk, tv, torch.from_numpy(cu_q).to(dev), torch.from_numpy(cu_k).to(dev), max(lens_q), max(lens_k),
+                               is_causal=c["causal"], smooth_k=c["smooth"])
+        ref = oracle.lowbit_fa_varlen(q, k, v, cu_q, cu_k, dtype=c["dtype"], is_causal=c["causal"], smooth_k=c["smooth"], tail="neg_inf",
+                                      amax_floor=1e-7)
+        _o_close(_np(o), ref, c["dtype"])

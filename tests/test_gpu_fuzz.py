@@ -1,6 +1,8 @@
 """Seeded fuzz of the public operators against the CPU oracle: random small shapes (ragged lengths, GQA, head dims,
 layouts, dtypes, causal, return_lse, int8 / int4-range / fp8-PV / un-quantised, packed batches).  Catches shape-dependent
 code paths (odd tile counts, single-tile sequences, masked instances ...) that hand-picked cases miss."""
+import os
+
 import numpy as np
 import pytest
 
@@ -8,6 +10,10 @@ from test_gpu_parity import TDT, _canon, _np, _o_close, _t, dev  # noqa: F401
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
+
+
+N_LOW_BIT = int(os.environ.get("LBFA_FUZZ_N", "40"))  # more seeds for a one-off hunt: LBFA_FUZZ_N=400 pytest tests/test_gpu_fuzz.py -m gpu
+N_OTHER = max(12, N_LOW_BIT // 3)
 
 
 def _rand_cfg(rng):
@@ -22,7 +28,7 @@ def _rand_cfg(rng):
                 lse=bool(rng.integers(0, 2)), smooth=bool(rng.integers(0, 4)), bias=float(rng.choice([0.0, 0.3, -0.5])))
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(N_LOW_BIT))
 def test_fuzz_low_bit_operators(oracle, dev, seed):
     import lowbit_quant_fa2_paddle_amd as lb
     rng = np.random.default_rng(1000 + seed)
@@ -46,7 +52,10 @@ def test_fuzz_low_bit_operators(oracle, dev, seed):
     o, o_ref = (out[0], ref[0]) if c["lse"] else (out, ref)
     assert tuple(o.shape) == q.shape, c
     if kind == "fp8":
-        _o_close(_np(o), o_ref, c["dtype"], atol=3e-2, rtol=3e-2)  # e4m3 P codes flip on 1-ulp exp2 differences (parity unpinned)
+        # e4m3 P has 3 mantissa bits: a 1-ulp exp2 difference at a rounding boundary flips a code (6 % of that P), which
+        # shows in rows with few keys (parity unpinned for this path) - loose element bound, tight mean-square bound
+        _o_close(_np(o), o_ref, c["dtype"], atol=6e-2, rtol=6e-2)
+        assert float(np.mean((_np(o) - o_ref) ** 2)) <= 2e-5, c
     else:
         _o_close(_np(o), o_ref, c["dtype"])
     if c["lse"]:
@@ -54,7 +63,7 @@ def test_fuzz_low_bit_operators(oracle, dev, seed):
         assert np.abs(_np(out[1]) - ref[1]).max() <= tol, c
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(N_OTHER))
 def test_fuzz_unquantised_and_varlen(oracle, dev, seed):
     import lowbit_quant_fa2_paddle_amd as lb
     rng = np.random.default_rng(2000 + seed)

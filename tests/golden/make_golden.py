@@ -222,6 +222,10 @@ CASES = [
     dict(name="int4_s256_d64_causal", B=1, H=2, S=256, D=64, seed=6, q_qmax=7, k_qmax=7, causal=True),
     dict(name="q8k4_s256_d128", B=1, H=2, S=256, D=128, seed=7, q_qmax=127, k_qmax=7),
     dict(name="nosmooth_s256_d64", B=1, H=2, S=256, D=64, seed=8, smooth_k=False),
+    # 4-bit-range codes with a padded head dim: pins fp32(sm_scale * 1.44269504) formed in double (a float-by-float
+    # product is one ulp off for D = 80 / 96 / 40 and flips codes)
+    dict(name="int4_pad_d80_bf16_s256", B=1, H=2, S=256, D=80, dtype="bf16", seed=9, q_qmax=7, k_qmax=7),
+    dict(name="int4_pad_d96_s256_causal", B=1, H=2, S=256, D=96, seed=10, q_qmax=7, k_qmax=7, causal=True),
 ]
 
 if __name__ == "__main__":

@@ -481,3 +481,29 @@ def test_packed_qkv_views_are_consumed_in_place(oracle, dev, pv):
     flat = qkv.reshape(B * S, 3, H, D)
     ov = lb.lowbit_fa_varlen(flat[:, 0], flat[:, 1], flat[:, 2], cu, cu, S, S, is_causal=True)
     assert tuple(ov.shape) == (B * S, H, D) and torch.isfinite(ov).all()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_operator_end_to_end_vs_reference_golden(oracle, dev, name):
+    """fp16 / bf16 inputs -> public operator (one lbfa_forward call: in-kernel Q quantiser, K quantiser, attention) against
+    the O that the reference's own quantiser + attention kernels produced for the same seeded inputs; and the in-kernel Q
+    codes, observed through q_scale, against the reference quantiser's scales (bit-exact via the modular entry point)."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    from lowbit_quant_fa2_paddle_amd import quant_per_block as qpb
+    p, g = load_golden(name)
+    q, k, v = oracle.make_inputs(p["B"], p["H"], p["S"], p["D"], seed=p["seed"], layout=p["layout"], dtype=p["dtype"], Hkv=p["Hkv"],
+                                 Sk=p["Sk"], k_bias=p["k_bias"])
+    tq, tk, tv = (_t(a, p["dtype"], dev) for a in (q, k, v))
+    kw = dict(tensor_layout=p["layout"], is_causal=p["causal"], smooth_k=p["smooth_k"])
+    if p["q_qmax"] == 127 and p["k_qmax"] == 127:
+        o = lb.lowbit_fa_qk_int8_pv_fp16_triton(tq, tk, tv, **kw)
+    else:
+        o = lb.lowbit_fa_qk_int4_pv_fp16_triton(tq, tk, tv, q_bits=4 if p["q_qmax"] == 7 else 8, **kw)
+    _o_close(_np(o), g["o"], p["dtype"])
+    # the Q quantiser on the padded tensor, with the scale factor formed as the reference's Python does (in double)
+    D = p["D"]
+    Dp = 64 if D <= 64 else 128
+    tqp = torch.nn.functional.pad(tq, (0, Dp - D)) if Dp != D else tq
+    q8, qs = qpb.quantize(tqp, sm_scale=D ** -0.5 * 1.44269504, qmax=p["q_qmax"], blk=128, tensor_layout=p["layout"])
+    assert np.array_equal(q8.cpu().numpy(), g["q_i8"])
+    assert np.array_equal(qs.cpu().numpy().view(np.uint32), g["q_scale"].view(np.uint32))

@@ -66,8 +66,16 @@ __global__ void mean_finalize_kernel(MeanParams p) {
   const int d = (int)(idx % p.D);
   const int64_t bh = idx / p.D;
   const float* src = p.partial + bh * p.nsplit * p.D + d;
+  // loads issued 16 at a time (a dependent chain of single loads made this tiny kernel latency-bound), added in split order
   float s = 0.f;
-  for (int i = 0; i < p.nsplit; ++i) s += src[(int64_t)i * p.D];
+  for (int i0 = 0; i0 < p.nsplit; i0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = (i0 + j < p.nsplit) ? src[(int64_t)(i0 + j) * p.D] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (i0 + j < p.nsplit) s += v[j];
+  }
   reinterpret_cast<unsigned short*>(p.out)[idx] = store_cvt<DT>(s / (float)p.S);
 }
 

@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 
 N_LOW_BIT = int(os.environ.get("LBFA_FUZZ_N", "40"))  # more seeds for a one-off hunt: LBFA_FUZZ_N=400 pytest tests/test_gpu_fuzz.py -m gpu
 N_OTHER = max(12, N_LOW_BIT // 3)
+SEED0 = int(os.environ.get("LBFA_FUZZ_SEED0", "0"))  # shifts the whole seed range for another hunt
 
 
 def _rand_cfg(rng):
@@ -32,7 +33,7 @@ def _rand_cfg(rng):
 @pytest.mark.parametrize("seed", range(N_LOW_BIT))
 def test_fuzz_low_bit_operators(oracle, dev, seed):
     import lowbit_quant_fa2_paddle_amd as lb
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + SEED0 + seed)
     c = _rand_cfg(rng)
     kind = ["int8", "int8", "int4", "q8k4", "fp8"][seed % 5]
     q, k, v = oracle.make_inputs(c["B"], c["H"], c["Sq"], c["D"], seed=seed, layout=c["layout"], dtype=c["dtype"], Hkv=c["Hkv"],
@@ -55,7 +56,8 @@ def test_fuzz_low_bit_operators(oracle, dev, seed):
     if kind == "fp8":
         # e4m3 P has 3 mantissa bits: a 1-ulp exp2 difference at a rounding boundary flips a code (6 % of that P), which
         # shows in rows with few keys (parity unpinned for this path) - loose element bound, tight mean-square bound
-        _o_close(_np(o), o_ref, c["dtype"], atol=6e-2, rtol=6e-2)
+        # (a causal row with k keys moves by up to ~6 % * |v| / sqrt(k) per flipped code: up to 0.1 for the first rows)
+        _o_close(_np(o), o_ref, c["dtype"], atol=0.2, rtol=6e-2)
         assert float(np.mean((_np(o) - o_ref) ** 2)) <= 2e-5, c
     else:
         _o_close(_np(o), o_ref, c["dtype"])
@@ -69,7 +71,7 @@ def test_fuzz_low_bit_operators(oracle, dev, seed):
 @pytest.mark.parametrize("seed", range(N_OTHER))
 def test_fuzz_unquantised_and_varlen(oracle, dev, seed):
     import lowbit_quant_fa2_paddle_amd as lb
-    rng = np.random.default_rng(2000 + seed)
+    rng = np.random.default_rng(2000 + SEED0 + seed)
     c = _rand_cfg(rng)
     if seed % 2 == 0:  # un-quantised kernel vs fp64 SDPA
         q, k, v = oracle.make_inputs(c["B"], c["H"], c["Sq"], c["D"], seed=seed, layout=c["layout"], dtype=c["dtype"], Hkv=c["Hkv"],

@@ -42,6 +42,8 @@ def _check_head_vs_oracle(oracle, fn_kwargs, q, k, v, o, layout, b, h, atol=2e-3
 @pytest.mark.parametrize("name,B,H,S,D,layout,causal", [
     ("C2", 4, 32, 4096, 64, "HND", False),
     ("C3", 4, 32, 16384, 128, "NHD", True),
+    # the reference's CogVideoX plug-in shape: S = 17776 is not a multiple of 64 or 128, H = 30
+    ("CogVideoX", 2, 30, 17776, 64, "HND", False),
 ])
 def test_int8_fp16_fullsize(oracle, dev, name, B, H, S, D, layout, causal):
     import lowbit_quant_fa2_paddle_amd as lb
@@ -73,7 +75,7 @@ def test_int8_fp16_fullsize(oracle, dev, name, B, H, S, D, layout, causal):
         first_v = v[:, :, 0] if layout == "HND" else v[:, 0]
         assert float((first_o.float() - first_v.float()).abs().max()) <= 1e-3
     # oracle spot check on one head (two for the smaller config)
-    for b, h in ([(0, 0), (3, 31)] if name == "C2" else [(2, 5)]):
+    for b, h in ([(0, 0), (3, 31)] if name == "C2" else [(min(2, B - 1), 5)]):
         _check_head_vs_oracle(oracle, {}, q, k, v, o, layout, b, h, is_causal=causal)
 
 

@@ -84,7 +84,7 @@ size_t lbfa_mean_seq_workspace_bytes(int B, int H, int S, int D) {
   if (B <= 0 || H <= 0 || S <= 0 || D <= 0) return 0;
   const int rps = lbfa::mean_rows_per_split(S);
   const size_t nsplit = (size_t)(S + rps - 1) / rps;
-  return (size_t)B * H * nsplit * D * sizeof(float);
+  return (size_t)B * H * nsplit * D * sizeof(double);
 }
 
 namespace {

@@ -17,7 +17,8 @@ namespace lbfa {
 // ---------------------------------------------------------------------------------------------------
 struct MeanParams {
   const unsigned short* x;
-  float* partial;   // [B,H,nsplit,D]
+  double* partial;  // [B,H,nsplit,D] - fp64 sums: the mean is the correctly rounded one (== a float64 reference mean), not
+                    // "within an ulp": with 4-bit-range codes a 1-ulp shift of km flips codes
   void* out;        // [B,H,D] storage dtype
   int64_t sb, sh, ss;
   int B, H, S, D, rows_per_split, nsplit;
@@ -28,30 +29,30 @@ template <int DT, int D>
 __global__ __launch_bounds__(256) void mean_partial_kernel(MeanParams p) {
   constexpr int CPR = D / 8;        // 16-byte chunks per row
   constexpr int RL = 256 / CPR;     // rows in flight per pass
-  __shared__ float red[RL][D + 1];
+  __shared__ double red[RL][D + 1];
   const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int t = threadIdx.x, c = t % CPR, rl = t / CPR;
   const unsigned short* base = p.x + (int64_t)b * p.sb + (int64_t)h * p.sh + c * 8;
   const int r0 = split * p.rows_per_split;
   const int r1 = min(r0 + p.rows_per_split, p.S);
-  float acc[8];
+  double acc[8];  // the kernel is HBM-bound: fp64 adds are free here
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int i = 0; i < 8; ++i) acc[i] = 0.0;
   if (c * 8 < p.d_valid)
   for (int r = r0 + rl; r < r1; r += RL) {
     const uint4 raw = *reinterpret_cast<const uint4*>(base + (int64_t)r * p.ss);
     const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      acc[2 * i] += load_cvt<DT>((unsigned short)(w[i] & 0xffffu));
-      acc[2 * i + 1] += load_cvt<DT>((unsigned short)(w[i] >> 16));
+      acc[2 * i] += (double)load_cvt<DT>((unsigned short)(w[i] & 0xffffu));
+      acc[2 * i + 1] += (double)load_cvt<DT>((unsigned short)(w[i] >> 16));
     }
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) red[rl][c * 8 + i] = acc[i];
   __syncthreads();
   if (t < D) {
-    float s = 0.f;
+    double s = 0.0;
 #pragma unroll 4
     for (int r = 0; r < RL; ++r) s += red[r][t];
     p.partial[(((int64_t)b * p.H + h) * p.nsplit + split) * D + t] = s;
@@ -65,18 +66,19 @@ __global__ void mean_finalize_kernel(MeanParams p) {
   if (idx >= n) return;
   const int d = (int)(idx % p.D);
   const int64_t bh = idx / p.D;
-  const float* src = p.partial + bh * p.nsplit * p.D + d;
+  const double* src = p.partial + bh * p.nsplit * p.D + d;
   // loads issued 16 at a time (a dependent chain of single loads made this tiny kernel latency-bound), added in split order
-  float s = 0.f;
+  double s = 0.0;
   for (int i0 = 0; i0 < p.nsplit; i0 += 16) {
-    float v[16];
+    double v[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = (i0 + j < p.nsplit) ? src[(int64_t)(i0 + j) * p.D] : 0.f;
+    for (int j = 0; j < 16; ++j) v[j] = (i0 + j < p.nsplit) ? src[(int64_t)(i0 + j) * p.D] : 0.0;
 #pragma unroll
     for (int j = 0; j < 16; ++j)
       if (i0 + j < p.nsplit) s += v[j];
   }
-  reinterpret_cast<unsigned short*>(p.out)[idx] = store_cvt<DT>(s / (float)p.S);
+  // float64 mean -> fp32 -> storage dtype: the roundings of `np.mean(float64).astype(float32)` -> fp16 / bf16
+  reinterpret_cast<unsigned short*>(p.out)[idx] = store_cvt<DT>((float)(s / (double)p.S));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -327,7 +329,7 @@ hipError_t launch_mean_seq(const void* x, int dtype, void* out, void* ws, int B,
   MeanParams p;
   p.d_valid = d_valid;
   p.x = (const unsigned short*)x;
-  p.partial = (float*)ws;
+  p.partial = (double*)ws;
   p.out = out;
   p.sb = st[0]; p.sh = st[1]; p.ss = st[2];
   p.B = B; p.H = H; p.S = S; p.D = D;

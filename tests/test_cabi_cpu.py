@@ -38,8 +38,8 @@ def test_header_symbols_exported(lib):
 
 
 def test_sizes_are_pure_functions(lib):
-    # [B,H,nsplit,D] fp32 with 256-row splits up to 16K keys
-    assert lib.lbfa_mean_seq_workspace_bytes(4, 32, 4096, 64) == 4 * 32 * 16 * 64 * 4
+    # [B,H,nsplit,D] fp64 partial sums with 256-row splits up to 16K keys
+    assert lib.lbfa_mean_seq_workspace_bytes(4, 32, 4096, 64) == 4 * 32 * 16 * 64 * 8
     assert lib.lbfa_mean_seq_workspace_bytes(0, 32, 4096, 64) == 0
     assert lib.lbfa_v_fp8_bytes(1, 2, 100, 64) == 1 * 2 * 2 * 64 * 64 + 1 * 2 * 64 * 4
 

@@ -92,3 +92,34 @@ def test_fuzz_unquantised_and_varlen(oracle, dev, seed):
         ref = oracle.lowbit_fa_varlen(q, k, v, cu_q, cu_k, dtype=c["dtype"], is_causal=c["causal"], smooth_k=c["smooth"], tail="neg_inf",
                                       amax_floor=1e-7, sm_scale=c["sm_scale"])
         _o_close(_np(o), ref, c["dtype"])
+
+
+@pytest.mark.parametrize("seed", range(max(10, N_LOW_BIT // 4)))
+def test_fuzz_modular_entry_points(oracle, dev, seed):
+    """mean_seq -> quantize (Q, K) -> attention through the modular C-ABI entry points on random shapes and on strided
+    (packed-qkv) views: km, codes and scales bit-exact against the oracle's intermediates, O within tolerance."""
+    from lowbit_quant_fa2_paddle_amd import attn_qk_int8_per_block as attn, quant_per_block as qpb
+    rng = np.random.default_rng(3000 + SEED0 + seed)
+    c = _rand_cfg(rng)
+    D = int(rng.choice([64, 128]))  # the modular entry points take padded head dims only
+    qm, km_ = [(127, 127), (7, 7), (127, 7)][seed % 3]
+    q, k, v = oracle.make_inputs(c["B"], c["H"], c["Sq"], D, seed=seed, layout=c["layout"], dtype=c["dtype"], Hkv=c["Hkv"], Sk=c["Sk"],
+                                 k_bias=c["bias"])
+    tq, tk, tv = (_t(a, c["dtype"], dev) for a in (q, k, v))
+    if seed % 2 and c["Sq"] == c["Sk"] and c["H"] == c["Hkv"] and c["layout"] == "NHD":  # strided views of one packed tensor
+        qkv = torch.stack([tq, tk, tv], dim=2)
+        tq, tk, tv = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    sm = c["sm_scale"] or D ** -0.5
+    o_ref, lse_ref, mid = oracle.lowbit_fa_forward(q, k, v, dtype=c["dtype"], tensor_layout=c["layout"], is_causal=c["causal"],
+                                                   smooth_k=c["smooth"], sm_scale=sm, q_qmax=qm, k_qmax=km_, return_lse=True,
+                                                   tail="neg_inf", amax_floor=1e-7, return_intermediates=True)
+    km = qpb.mean_seq(tk, c["layout"]) if c["smooth"] else None
+    if km is not None:
+        assert np.array_equal(_np(km).reshape(mid["km"].shape), mid["km"])
+    q8, qs = qpb.quantize(tq, sm_scale=sm * 1.44269504, qmax=qm, blk=128, tensor_layout=c["layout"])
+    k8, ks = qpb.quantize(tk, sm_scale=1.0, qmax=km_, blk=64, tensor_layout=c["layout"], mean=km)
+    assert np.array_equal(_canon(q8.cpu().numpy(), c["layout"]), mid["q_i8"]) and np.array_equal(_canon(k8.cpu().numpy(), c["layout"]), mid["k_i8"])
+    assert np.array_equal(qs.cpu().numpy().view(np.uint32), mid["q_scale"].view(np.uint32))
+    assert np.array_equal(ks.cpu().numpy().view(np.uint32), mid["k_scale"].view(np.uint32))
+    o, _ = attn.forward(q8, k8, tv, qs, ks, tensor_layout=c["layout"], output_dtype=TDT[c["dtype"]], is_causal=c["causal"])
+    _o_close(_np(o), o_ref, c["dtype"])

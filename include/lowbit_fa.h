@@ -57,9 +57,9 @@ const char* lbfa_last_error(void);
 
 /*
  * Mean over the sequence of x[B,H,S,D] -> mean_out[B,H,D] (contiguous, same dtype as x).
- * Replaces `km = k.mean(dim=seq_dim, keepdim=True)` (src/core.py:292-293); fp32 accumulation in a
- * fixed order (deterministic), rounded once to the storage dtype.
- * workspace: >= lbfa_mean_seq_workspace_bytes(B,H,S,D) bytes of device memory (fp32 partial sums).
+ * Replaces `km = k.mean(dim=seq_dim, keepdim=True)` (src/core.py:292-293); fp64 accumulation in a
+ * fixed order (deterministic): the correctly rounded mean (float64 mean -> fp32 -> storage dtype).
+ * workspace: >= lbfa_mean_seq_workspace_bytes(B,H,S,D) bytes of device memory (fp64 partial sums), 16-byte aligned.
  */
 size_t lbfa_mean_seq_workspace_bytes(int B, int H, int S, int D);
 int lbfa_mean_seq(const void* x, int dtype, void* mean_out, void* workspace, size_t workspace_bytes,

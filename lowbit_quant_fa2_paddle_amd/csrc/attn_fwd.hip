@@ -37,11 +37,20 @@ namespace lbfa {
 #ifndef LBFA_PRIO_FP8
 #define LBFA_PRIO_FP8 0  // fp8 PV (2 / 4 long block-scaled MFMAs per tile): measured best without it (+2.7 % C5, +4 % D=64)
 #endif
-#ifndef LBFA_VPRE
-#define LBFA_VPRE(D) 0  // measured: prefetch distances 2..8 change nothing beyond noise (other waves already hide the LDS latency)
+// fp16 P row sums: 0 = fp32 v_add on the VALU, 2 = on the matrix pipe (v_mfma_f32_4x4x4_16b_f16 with an all-ones A operand, each lane
+// sums its own values).  Measured (C2 / S=16K / D=128 / C3, TFLOP/s, same box): VALU 980 / 1120 / 1214 / 1289, MFMA 990 / 1137 /
+// 1190 / 1286, all-ones 32x32x16 MFMA (16 accumulator registers, two waves per SIMD at D = 64) 853 / 996: MFMA sums at D = 64
+// where the VALU is the busier pipe, VALU sums at D = 128 where the matrix pipe is.
+#ifndef LBFA_LSUM
+#define LBFA_LSUM(D) ((D) == 64 ? 2 : 0)
 #endif
-#ifndef LBFA_ONES_SUM
-#define LBFA_ONES_SUM 0  // measured: 4 extra MFMAs instead of 32 v_add per lane is 1-3 % SLOWER at D=64 (dependent MFMA chain before the overflow check)
+// 1: exponentiate / PV per 32-key block with the PV MFMAs of block 0 pinned between the exponentials of block 1
+// (sched_group_barrier).  +1 % at D = 64, -3 % at D = 128.
+#ifndef LBFA_ILV
+#define LBFA_ILV(D) ((D) == 64 ? 1 : 0)
+#endif
+#ifndef LBFA_DMA
+#define LBFA_DMA 1  // K / V tiles by LDS-DMA (buffer_load ... lds) instead of staging registers + ds_write: +3..5 %
 #endif
 #ifndef LBFA_THR
 #define LBFA_THR 8.0f
@@ -50,24 +59,31 @@ namespace lbfa {
 // block scales: twice the fp16 MFMA rate) - must match the V layout written by lbfa_quant_v_fp8 (quant_kernels.hip)
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-// Row sums of a 64-key tile through the matrix pipe: O_l^T = 1 P^T with an all-ones A operand - every
-// accumulator row is the column sum of P^T over both lane halves.
-template <typename PF>
-__device__ __forceinline__ float ones_rowsum(const PF (&pf)[4]) {
-  if constexpr (std::is_same<PF, f16x8>::value) {
-    const f16x8 ones = f16x8{(_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f,
-                             (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f};
-    f32x16 lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[0], f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
-#pragma unroll
-    for (int ks = 1; ks < 4; ++ks) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[ks], lacc, 0, 0, 0);
-    return lacc[0];
-  } else {
-    return 0.f;
-  }
+// l_acc += 1 P^T for one k-step of fp16 P: two v_mfma_f32_4x4x4_16b_f16 with an all-ones A operand (16 independent
+// 4x4 blocks: lane l supplies column l & 3 of block l >> 2 and gets that column's sums back, i.e. the sum of its own four
+// values, in all four accumulator registers).
+__device__ __forceinline__ void rowsum_mfma(f32x4& l_acc, const f16x8& pfrag) {
+  const f16x4 ones4 = f16x4{(_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f};
+  l_acc = __builtin_amdgcn_mfma_f32_4x4x4f16(ones4, f16x4{pfrag[0], pfrag[1], pfrag[2], pfrag[3]}, l_acc, 0, 0, 0);
+  l_acc = __builtin_amdgcn_mfma_f32_4x4x4f16(ones4, f16x4{pfrag[4], pfrag[5], pfrag[6], pfrag[7]}, l_acc, 0, 0, 0);
 }
 
+#ifdef LBFA_STAMPS  // diagnostic build only: where does a workgroup's time go (s_memtime at five points, wave 0 lane 0)
+__device__ long long g_stamps[8192 * 8];
+#define LBFA_STAMP(k)                                                                                             \
+  do {                                                                                                            \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();     \
+  } while (0)
+extern "C" int lbfa_debug_stamps(void* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), sizeof(g_stamps), 0, hipMemcpyDeviceToHost);
+}
+#else
+#define LBFA_STAMP(k)
+#endif
+
 template <int D, int QT, int VT, int OT, bool CAUSAL, bool QQ = false>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+// D = 64 fits three waves per SIMD (<= 168 registers): ask for it, or an instance one register over silently drops to two
+__global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnParams p) {
   static_assert(!QQ || QT == kQInt8, "in-kernel Q quantisation belongs to the int8 path");
   constexpr bool FP8 = (VT == LBFA_E4M3);
   // QT = kQInt8: the low-bit path.  QT = LBFA_F16 / LBFA_BF16: un-quantised Q and K (the FP16 branch of the
@@ -85,12 +101,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   constexpr int VBYTES = FP8 ? 64 * D : 128 * D;     // V tile
   constexpr int KCH = KBYTES / (256 * 16);           // 16-B chunks per thread
   constexpr int VCH = VBYTES / (256 * 16);
-#ifdef LBFA_LDS_PAD  // occupancy experiment: pad the LDS footprint to limit workgroups per CU
-  __shared__ __attribute__((aligned(16))) char smem[2 * (KBYTES + VBYTES) + LBFA_LDS_PAD];
-#else
-  __shared__ __attribute__((aligned(16))) char smem[2 * (KBYTES + VBYTES)];
-#endif
+  // K / V tiles go from global memory straight into LDS (`buffer_load_dwordx4 ... lds`): no staging registers, no
+  // ds_write pass.  Not for bf16 V, which is converted to fp16 on the way in (registers + ds_write).
+  constexpr bool DMA = (LBFA_DMA != 0);                        // K
+  constexpr bool DMA_V = (LBFA_DMA != 0) && (VT != LBFA_BF16);  // V
+  constexpr int TILES_BYTES = 2 * (KBYTES + VBYTES);
+  // ONE LDS object (a second one next to an LDS-DMA target makes hipcc drain vmcnt before every ds_read): the tile
+  // buffers + 16 bytes for the workgroup reductions (block amax, overflow vote), which must not alias a tile in flight
+  __shared__ __attribute__((aligned(16))) char smem[TILES_BYTES + 16];
 
+  LBFA_STAMP(0);
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -109,8 +129,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   int64_t qsc_base = (int64_t)b * p.qsc_b, ksc_base = (int64_t)b * p.ksc_b;
   if (p.cu_q != nullptr) {  // attn_qk_int8_block_varlen.py:125-141
     const int q0 = p.cu_q[b], k0 = p.cu_k[b];
-    Sq = p.cu_q[b + 1] - q0;
-    Sk = p.cu_k[b + 1] - k0;
+    // max_seqlen_q / max_seqlen_k (p.Sq / p.Sk) size the grid and the padded scale rows: a sequence longer than the
+    // caller's maximum is cut there, so that every access stays inside the buffers sized from those maxima
+    Sq = min(p.cu_q[b + 1] - q0, p.Sq);
+    Sk = min(p.cu_k[b + 1] - k0, p.Sk);
     if (qt * 128 >= Sq) return;  // whole workgroup, before any barrier
     nK = (Sk + 63) >> 6;
     q_off = (int64_t)q0 * p.qs;
@@ -152,8 +174,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   unsigned k_goff, k_loff, v_goff, v_loff;
   {
     const int row = t / KCPR, ch = t % KCPR;
+    // LDS-DMA writes a wave's 64 x 16 bytes linearly (thread t -> byte 16 t of the pass): the swizzle moves to the SOURCE
+    // address - the slot (row, ch) of the image holds global chunk ch ^ kx(row)
+    const int gch = DMA ? (ch ^ kx<RB>(row)) : ch;
     // padded channels: an offset beyond any window -> the range check returns zeros (windows are < 2 GiB, checked by the C ABI)
-    k_goff = ch * 16 < ESZ * dq_valid ? ESZ * (unsigned)row * (unsigned)p.ks + ch * 16 : 0x80000000u;
+    k_goff = gch * 16 < ESZ * dq_valid ? ESZ * (unsigned)row * (unsigned)p.ks + gch * 16 : 0x80000000u;
     k_loff = row * RB + ((ch ^ kx<RB>(row)) << 4);
   }
   if constexpr (FP8) {
@@ -161,43 +186,73 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     v_loff = 2 * KBYTES + t * 16;
   } else {
     const int row = t / VCPR, ch = t % VCPR;
-    v_goff = ch * 8 < p.d_valid ? 2 * ((unsigned)row * (unsigned)p.vs) + ch * 16 : 0x80000000u;
+    const int gch = DMA_V ? ((((ch >> 2) ^ vx<D>(row)) << 2) | (ch & 3)) : ch;
+    v_goff = gch * 8 < p.d_valid ? 2 * ((unsigned)row * (unsigned)p.vs) + gch * 16 : 0x80000000u;
     v_loff = 2 * KBYTES + row * (2 * D) + (((ch >> 2) ^ vx<D>(row)) << 6) + ((ch & 3) << 4);
   }
   const unsigned k_gstep = ESZ * KROWS * (unsigned)p.ks;                  // bytes between a thread's K chunks
   const unsigned v_gstep = FP8 ? 4096u : 2u * VROWS * (unsigned)p.vs;
   constexpr int K_LSTEP = KROWS * RB, V_LSTEP = FP8 ? 4096 : VROWS * 2 * D;
-  // ---- staging registers ----------------------------------------------------------------------------
-  u32x4 kreg[KCH], vreg[VCH];
+  static_assert(K_LSTEP == 4096 && V_LSTEP == 4096, "one pass of 256 threads x 16 bytes");
+  // ---- staging registers (register path only) ---------------------------------------------------------
+  u32x4 kreg[DMA ? 1 : KCH], vreg[DMA_V ? 1 : VCH];
   // windows are < 2 GiB (checked by the C ABI): remaining bytes in 32-bit scalar arithmetic (the lookahead tile past the
   // end gets a window of 0 bytes)
   const int k_bytes32 = (int)k_bytes, v_bytes32 = (int)v_bytes, k_stride32 = (int)k_tile_stride, v_stride32 = (int)v_tile_stride;
-  auto load_tile = [&](int j) {  // rows / tiles past the end are outside the descriptor and read as zeros
+  typedef __attribute__((address_space(3))) void* lds_void_ptr;
+  // fetch tile j (into LDS buffer `buf_tag` with DMA, into the staging registers otherwise)
+  auto load_tile = [&](int j, auto buf_tag) __attribute__((always_inline)) {  // rows / tiles past the end are outside the descriptor and read as zeros
+    constexpr int BUF = decltype(buf_tag)::value;
     const int ko = j * k_stride32, vo = j * v_stride32;
     const int k_rem = j < nK ? max(0, k_bytes32 - ko) : 0, v_rem = j < nK ? max(0, v_bytes32 - vo) : 0;
     const __amdgpu_buffer_rsrc_t k_rs = make_rsrc(kbase + (j < nK ? ko : 0), (unsigned)k_rem);
     const __amdgpu_buffer_rsrc_t v_rs = make_rsrc(vbase + (j < nK ? vo : 0), (unsigned)v_rem);
+    // DMA destination = wave-uniform base (+ 16 bytes per lane, implicit)
+    if constexpr (DMA) {
+      char* kdst = smem + BUF * KBYTES + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < KCH; ++i) kreg[i] = buf_load16(k_rs, k_goff, i * k_gstep);
+      for (int i = 0; i < KCH; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rs, (lds_void_ptr)(kdst + i * 4096), 16, (int)k_goff, (int)(i * k_gstep), 0, 0);
+    } else {
 #pragma unroll
-    for (int i = 0; i < VCH; ++i) vreg[i] = buf_load16(v_rs, v_goff, i * v_gstep);
-  };
-  auto store_tile = [&](auto buf_tag) {
-    constexpr int BUF = decltype(buf_tag)::value;
-#pragma unroll
-    for (int i = 0; i < KCH; ++i) {
-      u32x4 val = kreg[i];
-      *reinterpret_cast<u32x4*>(smem + k_loff + i * K_LSTEP + BUF * KBYTES) = val;
+      for (int i = 0; i < KCH; ++i) kreg[i] = buf_load16(k_rs, k_goff, i * k_gstep);
     }
+    if constexpr (DMA_V) {
+      char* vdst = smem + 2 * KBYTES + BUF * VBYTES + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < VCH; ++i) {
-      u32x4 val = vreg[i];
-      if constexpr (VT == LBFA_BF16) val = bf16x8_to_f16x8(val);  // bf16 -> fp16 on the way in (src/core.py:307-308 `v.to(float16)`)
-      *reinterpret_cast<u32x4*>(smem + v_loff + i * V_LSTEP + BUF * VBYTES) = val;
+      for (int i = 0; i < VCH; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rs, (lds_void_ptr)(vdst + i * 4096), 16, (int)v_goff, (int)(i * v_gstep), 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < VCH; ++i) vreg[i] = buf_load16(v_rs, v_goff, i * v_gstep);
+    }
+  };
+  auto store_tile = [&](auto buf_tag) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    if constexpr (!DMA) {
+#pragma unroll
+      for (int i = 0; i < KCH; ++i) {
+        u32x4 val = kreg[i];
+        *reinterpret_cast<u32x4*>(smem + k_loff + i * K_LSTEP + BUF * KBYTES) = val;
+      }
+    }
+    if constexpr (!DMA_V) {
+#pragma unroll
+      for (int i = 0; i < VCH; ++i) {
+        u32x4 val = vreg[i];
+        if constexpr (VT == LBFA_BF16) val = bf16x8_to_f16x8(val);  // bf16 -> fp16 on the way in (src/core.py:307-308 `v.to(float16)`)
+        *reinterpret_cast<u32x4*>(smem + v_loff + i * V_LSTEP + BUF * VBYTES) = val;
+      }
     }
   };
 
-  load_tile(0);  // first K / V tile: in flight while Q is fetched (and quantised)
+  load_tile(0, std::integral_constant<int, 0>{});  // first K / V tile: in flight while Q is fetched (and quantised)
+  // ... and so are the dequantisation scales of the first 64 key tiles (lane l: tile l), needed right after the Q prologue
+  const float* ksc = nullptr;
+  if constexpr (!QK16) ksc = p.k_scale + ksc_base + (int64_t)hk * p.ksc_h;
+  const int ksc_blk = (int)p.ksc_blk;
+  float ks_first = 0.f;
+  if constexpr (!QK16) ks_first = lane < nK ? ksc[lane * ksc_blk] : 0.f;
 
   // ---- Q fragments (B operand of the score MFMA): lane (r, hh) holds bytes [32s+16hh, +16) of its row.
   // Rows >= Sq are out of the descriptor's range and read as zeros.
@@ -235,17 +290,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         }
       }
     row_corr = load_cvt<OT>(store_cvt<OT>(half_swap_sum(dot)));  // rounded to the storage dtype (src/core.py:294-304)
-    amax = wave_max(amax);
-    float* red = reinterpret_cast<float*>(smem);
+    amax = wave_max_nonneg(amax);
+    float* red = reinterpret_cast<float*>(smem + TILES_BYTES);
     if (lane == 0) red[wave] = amax;
     __syncthreads();
     amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();  // smem is about to be overwritten by the first K / V tile
+    __syncthreads();  // red[] is read by everyone before the overflow vote may reuse it
     const float scale = fmaxf(amax, 1e-7f) / p.q_qmax;
     qsc = scale;
     const float rcp = 1.0f / scale;
     const bool exact_rcp_ok = (__builtin_amdgcn_readfirstlane(__float_as_uint(scale)) & 0x7fffffu) != 0x7fffffu;
-    auto encode = [&](auto fast_tag) {  // block-uniform choice, two straight-line instances (as in quant_kernels.hip)
+    auto encode = [&](auto fast_tag) __attribute__((always_inline)) {  // block-uniform choice, two straight-line instances (as in quant_kernels.hip)
       constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
@@ -285,9 +340,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     }
     if constexpr (!QK16) qsc = p.q_scale[qsc_base + (int64_t)h * p.qsc_h + (int64_t)qt * p.qsc_blk];
   }
-  const float* ksc = nullptr;
-  if constexpr (!QK16) ksc = p.k_scale + ksc_base + (int64_t)hk * p.ksc_h;
-  const int ksc_blk = (int)p.ksc_blk;
+  LBFA_STAMP(1);
 
   int n_tiles = nK;
   if constexpr (CAUSAL) n_tiles = min(nK, 2 * (qt + 1));
@@ -319,18 +372,34 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   }
 
   // ---- running state --------------------------------------------------------------------------------
+  // Row sums.  Each lane sums the keys IT has seen (its half of every tile); both halves of a row share m_run, hence every
+  // rescale factor, so the halves are added once, in the epilogue.  MSUM (fp16 P, D = 64): the sum lives on the matrix pipe -
+  // l_acc accumulates 1 P^T with an all-ones A operand next to the PV MFMAs (v_mfma_f32_4x4x4_16b_f16: every lane sums
+  // its own values), so the 32 v_add_f32 per lane and tile disappear.  Otherwise fp32 adds into l_run (fp8 P: the reference
+  // sums before rounding, qk_int_sv_f8_cuda.cu:430-445).  Nothing inside the tile loop reads either sum.
+  constexpr bool MSUM = !FP8 && (LBFA_LSUM(D) == 2);
+  typedef f32x4 lacc_t;
   f32x16 acc_o[DB];
+  lacc_t l_acc;
+  float m_run;  // reference max (base-2 domain), identical in both halves of a row
+  float l_run;
+  auto reset_state = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int db = 0; db < DB; ++db)
+    for (int db = 0; db < DB; ++db)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc_o[db][i] = 0.f;
-  float m_run = -INFINITY;  // reference max (base-2 domain), identical in both halves of a row
-  float l_run = 0.f;        // running row sum over the keys THIS lane has seen (its half of every tile); halves are added in the epilogue
+      for (int i = 0; i < 16; ++i) acc_o[db][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(lacc_t) / 4); ++i) l_acc[i] = 0.f;
+    m_run = -INFINITY;
+    l_run = 0.f;
+  };
+  reset_state();
 
   // The int8 MFMA accumulates on top of this constant block (kept in registers for the whole kernel).
   i32x16 cmagic;
 #pragma unroll
   for (int i = 0; i < 16; ++i) cmagic[i] = kMagicBits;
+  asm volatile("" : "+v"(cmagic));  // opaque: otherwise the block is re-materialised from SGPRs with 8 v_mov_b64 in every tile
 
   // ---- exact bias folding --------------------------------------------------------------------------------
   // With tv = kMagic + s (the accumulator bits) the exponent argument is ONE fma:
@@ -343,34 +412,38 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   // typical data).  |c1| <= 1.17*kMagic*sc_max < 2^21*G, so every constant is an exact multiple of G.
   float ks_max = 0.f;
   if constexpr (!QK16) {
-    for (int i = lane; i < nK; i += 64) ks_max = fmaxf(ks_max, ksc[i * ksc_blk]);
-    ks_max = __builtin_amdgcn_readfirstlane(__float_as_uint(wave_max(ks_max))) ? wave_max(ks_max) : 1e-30f;
+    ks_max = ks_first;
+    for (int i = lane + 64; i < nK; i += 64) ks_max = fmaxf(ks_max, ksc[i * ksc_blk]);
+    ks_max = fmaxf(wave_max_nonneg(ks_max), 1e-30f);  // scales are positive (the quantiser floors amax)
   }
   const float sc_max = qsc * ks_max;
   const int gexp = (int)((__float_as_uint(1.25f * kMagic * sc_max) >> 23) & 0xff) - 127 + 1 - 21;  // log2(G)
   const float G = __builtin_ldexpf(1.0f, gexp), invG = __builtin_ldexpf(1.0f, -gexp);
   const float g = __builtin_ldexpf(1.0f, gexp - 22), invg = __builtin_ldexpf(1.0f, 22 - gexp);
-  auto grid_up = [&](float m) { return __builtin_ceilf(m * invG) * G; };  // -inf stays -inf
+  auto grid_up = [&](float m) __attribute__((always_inline)) { return __builtin_ceilf(m * invG) * G; };  // -inf stays -inf
   // Per-tile constants sc (dequantisation scale on the g grid) and c0 = -kMagic * sc are the same for every lane: lane l
   // of the wave computes them for tile 64 c + l once per chunk of 64 tiles, and each tile fetches its pair with two
   // v_readlane (no per-tile global load, no per-tile float math on uniform values).
   float sc_tab = 0.f, c0_tab = 0.f;
-  auto refresh_scale_table = [&](int j0) {
+  auto refresh_scale_table = [&](int j0) __attribute__((always_inline)) {
     if constexpr (!QK16) {
       const int jt = j0 + lane;
-      const float ks_l = jt < nK ? ksc[jt * ksc_blk] : 0.f;
-      sc_tab = __builtin_rintf(qsc * ks_l * invg) * g;
+      const float ks_l = j0 == 0 ? ks_first : (jt < nK ? ksc[jt * ksc_blk] : 0.f);
+      // at least one grid step: a block whose scale is < 2^-22 of the largest one (an all-zero K block) must not get
+      // sc = 0, or a masked key (tv = -inf) would turn into fma(-inf, 0, c1) = NaN
+      sc_tab = fmaxf(__builtin_rintf(qsc * ks_l * invg), 1.0f) * g;
       c0_tab = -kMagic * sc_tab;  // exact
     }
   };
-  refresh_scale_table(0);
 
-  constexpr float kPLimit = 32768.0f;  // fp16 P must stay finite (max 65504)
-
-  auto compute_tile = [&](auto buf_tag, int j, auto masked_tag) {
+  // One 64-key tile.  EXACT = take the exact row max before exponentiating (masked tiles, fp8 P, the exact re-run);
+  // otherwise the tile is exponentiated against the reference as it stands (see `lazy softmax reference` below).
+  // PRIME = scores + reference only (first tile of the lazy pass).
+  auto compute_tile = [&](auto buf_tag, int j, auto masked_tag, auto exact_tag, auto prime_tag) __attribute__((always_inline)) {
     constexpr int BUF = decltype(buf_tag)::value;
     constexpr bool MASKED = decltype(masked_tag)::value;
-    constexpr bool LAZY = !MASKED && !FP8;  // skip the row-max pass unless P overflowed (see below)
+    constexpr bool EXACT = decltype(exact_tag)::value || MASKED || FP8;
+    constexpr bool PRIME = decltype(prime_tag)::value;
     const char* kbuf = smem + BUF * KBYTES;
     const char* vbuf = smem + BUF * VBYTES;
     // -- online softmax, base 2
@@ -382,51 +455,47 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc_tab), j & 63));
       c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c0_tab), j & 63));
     }
-    float x[2][16];  // scores as floats kMagic + s (accumulator bits), then overwritten in place by P
-    // -- S^T = K Q^T (int8 -> int32, biased by kMagic): two 32-key blocks
-    auto compute_scores = [&]() {
-      if constexpr (PRIO & 1) __builtin_amdgcn_s_setprio(1);
+    float x[2][16];  // scores as floats kMagic + s (accumulator bits); fp32 P path: overwritten in place by P
+    // -- S^T = K Q^T (int8 -> int32, biased by kMagic): one 32-key block
+    auto compute_scores = [&](auto kb2_tag) __attribute__((always_inline)) {
+      constexpr int kb2 = decltype(kb2_tag)::value;
+      i32x16 sacc;
+      f32x16 facc;
 #pragma unroll
-      for (int kb2 = 0; kb2 < 2; ++kb2) {
-        i32x16 sacc;
-        f32x16 facc;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const unsigned kfa = KF_XOR ? (kf_lane ^ (unsigned)(s << 5)) : kf_base[KF_XOR ? 0 : s];
-          const i32x4 kf = *reinterpret_cast<const i32x4*>(kbuf + kfa + kb2 * 32 * RB);
-          if constexpr (QT == LBFA_BF16) {  // bf16 Q / K go to the bf16 MFMA as they are: exact products, full bf16 range
-            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-            const bf16x8 ka = __builtin_bit_cast(bf16x8, kf), qb = __builtin_bit_cast(bf16x8, qf[s]);
-            if (s == 0) facc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qb, f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
-            else facc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qb, facc, 0, 0, 0);
-          } else if constexpr (QK16) {
-            const f16x8 ka = __builtin_bit_cast(f16x8, kf), qb = __builtin_bit_cast(f16x8, qf[s]);
-            if (s == 0) facc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qb, f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
-            else facc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qb, facc, 0, 0, 0);
-          } else {
-            if (s == 0) sacc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], cmagic, 0, 0, 0);
-            else sacc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], sacc, 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float tv;
-          if constexpr (QK16) tv = facc[i];
-          else tv = __int_as_float(sacc[i]);
-          if constexpr (MASKED) {
-            const int key = j * 64 + 32 * kb2 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            bool dead = key >= Sk;
-            if constexpr (CAUSAL) dead = dead || (key > qrow);
-            if (dead) tv = -INFINITY;  // fma(-inf, sc, c1) = -inf -> p = 0
-          }
-          x[kb2][i] = tv;
+      for (int s = 0; s < KS; ++s) {
+        const unsigned kfa = KF_XOR ? (kf_lane ^ (unsigned)(s << 5)) : kf_base[KF_XOR ? 0 : s];
+        const i32x4 kf = *reinterpret_cast<const i32x4*>(kbuf + kfa + kb2 * 32 * RB);
+        if constexpr (QT == LBFA_BF16) {  // bf16 Q / K go to the bf16 MFMA as they are: exact products, full bf16 range
+          typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+          const bf16x8 ka = __builtin_bit_cast(bf16x8, kf), qb = __builtin_bit_cast(bf16x8, qf[s]);
+          if (s == 0) facc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qb, f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+          else facc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qb, facc, 0, 0, 0);
+        } else if constexpr (QK16) {
+          const f16x8 ka = __builtin_bit_cast(f16x8, kf), qb = __builtin_bit_cast(f16x8, qf[s]);
+          if (s == 0) facc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qb, f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+          else facc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qb, facc, 0, 0, 0);
+        } else {
+          if (s == 0) sacc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], cmagic, 0, 0, 0);
+          else sacc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qf[s], sacc, 0, 0, 0);
         }
       }
-      if constexpr (PRIO & 1) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float tv;
+        if constexpr (QK16) tv = facc[i];
+        else tv = __int_as_float(sacc[i]);
+        if constexpr (MASKED) {
+          const int key = j * 64 + 32 * kb2 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          bool dead = key >= Sk;
+          if constexpr (CAUSAL) dead = dead || (key > qrow);
+          if (dead) tv = -INFINITY;  // fma(-inf, sc, c1) = -inf -> p = 0  (sc > 0, see refresh_scale_table)
+        }
+        x[kb2][i] = tv;
+      }
     };
     // Move the reference m_run up to (at least) this tile's row max, rescaling O and l, when some row of the
     // wave needs it.  First tile: m_run = -inf -> alpha = 0.
-    auto update_reference = [&](float thr) {
+    auto update_reference = [&](float thr) __attribute__((always_inline)) {
       float tmax = -INFINITY;
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2)
@@ -441,37 +510,34 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);  // m_run = -inf -> 0
         m_run = m_cand;
         l_run *= alpha;
+        if constexpr (MSUM) {
+#pragma unroll
+          for (int i = 0; i < (int)(sizeof(lacc_t) / 4); ++i) l_acc[i] *= alpha;
+        }
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc_o[db][i] *= alpha;
       }
     };
-    // Row sums.  l_run holds this lane's half of the row (32 of every 64 keys): both halves of a row share m_run, hence
-    // every rescale factor, so the halves can be combined once, in the epilogue.
-    //  * ONES path (lazy fp16 tiles when the matrix pipe has slack, i.e. D = 64): the sum comes from four extra
-    //    MFMAs with an all-ones A operand, O_l^T = 1 P^T - every accumulator row is the column sum of P^T, over
-    //    both halves - instead of 32 v_add_f32 per lane on the saturated VALU;
-    //  * otherwise: fp32 adds of this lane's 32 values, halves combined with one v_permlane32_swap.
-    constexpr bool ONES = LAZY && (LBFA_ONES_SUM != 0) && (D == 64);
     typedef typename std::conditional<FP8, long, f16x8>::type pfrag_t;
     pfrag_t pf[4];
     i32x8 pf8;  // fp8: all 32 P values of the lane = one B operand (k = 32 hh + 16 kb2 + i)
-    float tile_sum = 0.f;
-    auto exponentiate = [&]() {  // x <- P in place, pf <- packed P^T fragments, tile_sum <- row sum of the tile
-      float c1 = c0 - m_run;  // exact (grid argument above); +inf while m_run = -inf
-      if constexpr (FP8) c1 += kFp8Offset;
-      float psum = 0.f;
+    float psum = 0.f;
+    // P of one 32-key block: x <- P (fp32 paths), pf / pf8 <- packed P^T fragments (k-steps 2 kb2, 2 kb2 + 1)
+    auto exponentiate = [&](auto kb2_tag, float c1) __attribute__((always_inline)) {
+      constexpr int kb2 = decltype(kb2_tag)::value;
 #pragma unroll
-      for (int kb2 = 0; kb2 < 2; ++kb2)
+      for (int i = 0; i < 16; ++i) {
+        x[kb2][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kb2][i], sc, c1));
+        if constexpr (!MSUM) psum += x[kb2][i];
+        // keep P in the score registers: left alone, the scheduler issues all exponentials first and sinks the adds, which
+        // needs 32 more registers (three waves per SIMD no longer fit at D = 64)
+        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          x[kb2][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kb2][i], sc, c1));
-          if constexpr (!ONES) psum += x[kb2][i];
-        }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int kb2 = ks >> 1, rb = (ks & 1) * 8;
+      for (int g8 = 0; g8 < 2; ++g8) {
+        const int ks = 2 * kb2 + g8, rb = 8 * g8;
         if constexpr (FP8) {
           unsigned w0 = 0, w1 = 0;
           w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[kb2][rb + 0], x[kb2][rb + 1], w0, false);
@@ -485,53 +551,66 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
           for (int e = 0; e < 8; ++e) pf[ks][e] = (_Float16)x[kb2][rb + e];
         }
       }
-      if constexpr (ONES) {
-        tile_sum = ones_rowsum(pf);  // sum of the fp16-rounded P over all 64 keys; +inf / NaN if any P overflowed
-      } else {
-        tile_sum = psum;     // this lane's 32 keys; halves are combined below
-      }
     };
-    // V^T fragments do not depend on P: request the first NPRE of them now, so they land while the VALU
-    // exponentiates, and keep requesting NPRE MFMAs ahead inside the PV loop (with only 2-3 waves per SIMD an
-    // LDS read issued right before its MFMA costs that MFMA the full LDS latency).
-    constexpr int NMF = 4 * DB;                       // PV MFMAs of the tile, index = ks * DB + db
-    constexpr int NPRE = FP8 ? 0 : LBFA_VPRE(D);      // software prefetch distance (fp16 V)
-    f16x4 vlo[NMF], vhi[NMF];                          // fully unrolled: only NPRE+1 of them are live at a time
-    auto v_request = [&](auto idx_tag) {
-      constexpr int idx = decltype(idx_tag)::value;
-      constexpr int ks = idx / DB, db = idx % DB;
+    // O^T += V^T P^T for the two k-steps of one 32-key block (P^T fragments straight from the score accumulators),
+    // and the row sums 1 P^T
+    auto pv_half = [&](auto kb2_tag) __attribute__((always_inline)) {
+      constexpr int kb2 = decltype(kb2_tag)::value;
       if constexpr (!FP8) {
-        vlo[idx] = lds_read_tr16(vbuf + vf_base[db] + ks * 32 * D);
-        vhi[idx] = lds_read_tr16(vbuf + vf_base[db] + ks * 32 * D + 16 * D);
+        static_for<0, 2 * DB>([&](auto i) {
+          constexpr int idx = decltype(i)::value;
+          constexpr int ks = 2 * kb2 + idx / DB, db = idx % DB;
+          const f16x4 vlo = lds_read_tr16(vbuf + vf_base[db] + ks * 32 * D);
+          const f16x4 vhi = lds_read_tr16(vbuf + vf_base[db] + ks * 32 * D + 16 * D);
+          const f16x8 vf = f16x8{vlo[0], vlo[1], vlo[2], vlo[3], vhi[0], vhi[1], vhi[2], vhi[3]};
+          acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ks], acc_o[db], 0, 0, 0);
+          if constexpr (MSUM && db == DB - 1) rowsum_mfma(l_acc, pf[ks]);
+        });
       }
     };
-    static_for<0, NPRE>([&](auto i) { v_request(i); });
 
-    if constexpr (LAZY) {
-      // Any reference within 2^15 of the row max is as good as the max itself (P is fp16/fp32 floating point):
-      // exponentiate against the current reference and look at the row sum, which bounds every P from above.
-      // Only if a sum blew up (first tile: reference = -inf -> +inf) redo the tile the long way: recompute the
-      // scores (K is still in LDS), take the row max, move the reference, exponentiate again.  Written as a
-      // loop so the rare second pass reuses the same code and registers.
-      bool redo = (j == 0);  // first tile: the reference is still -inf, the attempt could only overflow - go the long way at once
-#pragma clang loop unroll(disable)
-      for (;;) {
-        compute_scores();
-        if (redo) update_reference(0.0f);
-        exponentiate();
-        if (redo || !__any(!(tile_sum <= kPLimit))) break;
-        redo = true;
-      }
-    } else {
-      compute_scores();
-      update_reference(THR);
-      exponentiate();
+    compute_scores(std::integral_constant<int, 0>{});
+    compute_scores(std::integral_constant<int, 1>{});
+    if constexpr (PRIME) {
+      update_reference(0.0f);
+      return;
     }
-    if constexpr (ONES) l_run += 0.5f * tile_sum;  // the MFMA row sum already covers both halves
-    else l_run += tile_sum;
-
-    // -- O^T += V^T P^T : P^T fragments straight from the score accumulators
-    if constexpr (PRIO & 2) __builtin_amdgcn_s_setprio(1);
+    // `lazy softmax reference` (fp16 P, unmasked tiles, first pass): any reference within 2^15 of the row max is as good
+    // as the max itself (P is floating point, fp32 accumulate), so the row-max pass (16 v_max3 + a cross-half swap) is
+    // skipped and the tile is exponentiated against the reference the first tile set.  A row whose scores outgrow that
+    // reference by more than 2^16 overflows fp16 P: the infinity reaches the row's outputs (and l_acc), is seen ONCE after
+    // the loop, and the Q block is redone with the exact row max in every tile (`run_tiles`).  No per-tile check.
+    if constexpr (EXACT) update_reference(THR);
+    float c1 = c0 - m_run;  // exact (grid argument above); +inf while m_run = -inf
+    if constexpr (FP8) c1 += kFp8Offset;
+    exponentiate(std::integral_constant<int, 0>{}, c1);
+    constexpr bool ILV = (LBFA_ILV(D) != 0) && !FP8;
+    if constexpr (ILV) {
+      // One wave issues in order: back-to-back MFMAs hold its issue slot and overlap nothing of its own.  Pin the PV MFMAs
+      // of block 0 BETWEEN the exponentials of block 1 (one MFMA per few VALU instructions: each MFMA runs in the shadow of
+      // the VALU work that follows it).
+      __builtin_amdgcn_sched_barrier(0);
+      pv_half(std::integral_constant<int, 0>{});
+      exponentiate(std::integral_constant<int, 1>{}, c1);
+      constexpr int NM = 2 * DB + (MSUM ? 4 : 0);  // MFMAs of the block: PV + row sums
+      constexpr int NV = (MSUM ? 40 : 56) / NM;    // 16 fma + 16 exp + 8 cvt (+ 16 add) spread over them
+      static_for<0, NM>([&](auto) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      pv_half(std::integral_constant<int, 1>{});
+    } else {
+      // one long VALU phase, then one long MFMA phase under s_setprio: at D = 128 measured faster than two half-tile
+      // rounds (the other wave of the SIMD exponentiates in the shadow of this wave's MFMAs)
+      exponentiate(std::integral_constant<int, 1>{}, c1);
+      __builtin_amdgcn_sched_barrier(0);  // phase fence: keeps V fragment reads and row-sum adds where they are (registers)
+      if constexpr (PRIO & 2) __builtin_amdgcn_s_setprio(1);
+      pv_half(std::integral_constant<int, 0>{});
+      pv_half(std::integral_constant<int, 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (!MSUM) l_run += psum;
     if constexpr (FP8) {
       static_for<0, DB>([&](auto i) {
         constexpr int db = decltype(i)::value;
@@ -543,21 +622,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       });
       // Toolchain work-around (ROCm 7.2 / clang 22): the wait states the compiler leaves between this 16-pass MFMA and
       // a VALU read of its result (register copies at control-flow edges, the epilogue) are too few - the last two
-      // accumulator registers were read stale (tests: odd tile counts).  LBFA_MX_NOP more wait states close the gap.
+      // accumulator registers were read stale (tests: odd tile counts).  LBFA_MX_NOP more wait states close the gap
+      // (checked on the shipped code object by tools/check_mfma_hazards.py).
 #ifndef LBFA_MX_NOP
 #define LBFA_MX_NOP 7
 #endif
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_nop %0" ::"n"(LBFA_MX_NOP));
       __builtin_amdgcn_sched_barrier(0);
-    } else {
-      static_for<0, NMF>([&](auto i) {
-        constexpr int idx = decltype(i)::value;
-        constexpr int ks = idx / DB, db = idx % DB;
-        if constexpr (idx + NPRE < NMF) v_request(std::integral_constant<int, idx + NPRE>{});
-        const f16x8 vf = f16x8{vlo[idx][0], vlo[idx][1], vlo[idx][2], vlo[idx][3], vhi[idx][0], vhi[idx][1], vhi[idx][2], vhi[idx][3]};
-        acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ks], acc_o[db], 0, 0, 0);
-      });
     }
     if constexpr (PRIO & 2) __builtin_amdgcn_s_setprio(0);
   };
@@ -571,35 +643,77 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
-  auto step = [&](auto buf_tag, auto nbuf_tag, int j, auto masked_tag) {
+  using No = std::false_type;
+  using Yes = std::true_type;
+  auto step = [&](auto buf_tag, auto nbuf_tag, int j, auto masked_tag, auto exact_tag) __attribute__((always_inline)) {
     if ((j & 63) == 0 && j != 0) refresh_scale_table(j);  // wave-uniform, once per 64 tiles
-    load_tile(j + 1);
+    load_tile(j + 1, nbuf_tag);
     bool skip = false;
     if constexpr (decltype(masked_tag)::value && CAUSAL) skip = j * 64 > row0 + 31;  // all keys above all rows of this wave
-    if (!skip) compute_tile(buf_tag, j, masked_tag);
+    if (!skip) compute_tile(buf_tag, j, masked_tag, exact_tag, No{});
     store_tile(nbuf_tag);
-    __syncthreads();  // measured: dropping every per-tile barrier (wrong results, timing only) gains 0.8 % at D=64, 3.8 % at D=128
+    __syncthreads();  // with LDS-DMA in flight this waits vmcnt(0) first: tile j + 1 has landed when the barrier opens
+  };
+  // All tiles of this Q block.  Tile 0 is in flight (load_tile(0)) or being re-fetched on entry.
+  auto run_tiles = [&](auto exact_tag) __attribute__((always_inline)) {
+    constexpr bool EX = decltype(exact_tag)::value || FP8;
+    refresh_scale_table(0);
+    store_tile(B0{});
+    __syncthreads();
+    if constexpr (!EX) {
+      if (n_main > 0) compute_tile(B0{}, 0, No{}, No{}, Yes{});  // reference <- exact row max of the first tile
+    }
+    int j = 0;
+    for (; j + 1 < n_main; j += 2) {
+      step(B0{}, B1{}, j, No{}, exact_tag);
+      step(B1{}, B0{}, j + 1, No{}, exact_tag);
+    }
+    // here j is even: tile j lives in buffer 0
+    for (; j < n_tiles; j += 2) {
+      if (j < n_main) step(B0{}, B1{}, j, No{}, exact_tag);
+      else step(B0{}, B1{}, j, Yes{}, exact_tag);
+      if (j + 1 < n_tiles) {
+        if (j + 1 < n_main) step(B1{}, B0{}, j + 1, No{}, exact_tag);
+        else step(B1{}, B0{}, j + 1, Yes{}, exact_tag);
+      }
+    }
   };
 
-  store_tile(B0{});
-  __syncthreads();
-  int j = 0;
-  for (; j + 1 < n_main; j += 2) {
-    step(B0{}, B1{}, j, std::false_type{});
-    step(B1{}, B0{}, j + 1, std::false_type{});
-  }
-  // here j is even: tile j lives in buffer 0
-  for (; j < n_tiles; j += 2) {
-    if (j < n_main) step(B0{}, B1{}, j, std::false_type{});
-    else step(B0{}, B1{}, j, std::true_type{});
-    if (j + 1 < n_tiles) {
-      if (j + 1 < n_main) step(B1{}, B0{}, j + 1, std::false_type{});
-      else step(B1{}, B0{}, j + 1, std::true_type{});
+  LBFA_STAMP(2);
+  run_tiles(No{});
+  LBFA_STAMP(3);
+  float l_tot;
+  auto row_sum = [&]() __attribute__((always_inline)) {
+    l_tot = half_swap_sum(MSUM ? l_acc[0] : l_run);
+  };
+  row_sum();
+  if constexpr (!FP8) {
+    // Did any P overflow fp16 anywhere in this Q block?  An infinite P makes every output channel of its row +-inf or NaN
+    // (inf * 0) and, with row sums on the matrix pipe, the row sum too.  The four waves share the K / V tiles and the
+    // barriers, so the decision is taken for the workgroup.  The last step ended with a barrier: smem is free.
+    int* flag = reinterpret_cast<int*>(smem + TILES_BYTES);
+    float chk = l_tot;
+    if constexpr (!MSUM) {
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) chk += fabsf(acc_o[db][i]);
+    }
+    const int bad = __any(!(chk < INFINITY)) ? 1 : 0;
+    if (lane == 0) flag[wave] = bad;
+    __syncthreads();
+    const int any_bad = flag[0] | flag[1] | flag[2] | flag[3];
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(any_bad)) {
+      reset_state();
+      load_tile(0, B0{});
+      run_tiles(Yes{});
+      row_sum();
     }
   }
 
+  LBFA_STAMP(4);
   // ---- epilogue: O = O^T / l (x v_scale), LSE ------------------------------------------------------------
-  const float l_tot = half_swap_sum(l_run);
   const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;  // a sequence without keys (packed batches only) yields zeros
   if (qrow < Sq) {
     unsigned short* op = reinterpret_cast<unsigned short*>(p.o) + o_off + (int64_t)h * p.oh + (int64_t)qrow * p.os;
@@ -632,6 +746,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       p.lse[li] = ls;
     }
   }
+  LBFA_STAMP(5);
 }
 
 hipError_t launch_attn_fwd(const AttnParams& p, int D, int v_dtype, int o_dtype, int causal, hipStream_t stream) {

@@ -6,7 +6,7 @@ name=$1; extra=$2
 out=variants/lib_$name.so
 mkdir -p variants /tmp/lbfa_var_$name
 C=lowbit_quant_fa2_paddle_amd/csrc
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt $extra"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize $extra"
 rm -f /tmp/lbfa_var_$name/*.o $out
 pids=""
 for f in lbfa_api quant_kernels attn_fwd; do

@@ -627,9 +627,11 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
 #ifndef LBFA_MX_NOP
 #define LBFA_MX_NOP 7
 #endif
+#if LBFA_MX_NOP >= 0  // (-1: build without the pad, for tools/check_mfma_hazards.py to show what the compiler leaves)
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_nop %0" ::"n"(LBFA_MX_NOP));
       __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     if constexpr (PRIO & 2) __builtin_amdgcn_s_setprio(0);
   };

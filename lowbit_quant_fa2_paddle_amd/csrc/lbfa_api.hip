@@ -335,6 +335,27 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
   const FwdLayout L = fwd_layout(B, Hq, Hkv, Sq, Sk, D, pv_fp8, want_corr);
   if (workspace_bytes < L.total) return fail(LBFA_EINVAL, "lbfa_forward: workspace too small (%zu < %zu)", workspace_bytes, L.total);
   if (!aligned16(workspace)) return fail(LBFA_EINVAL, "lbfa_forward: workspace must be 16-byte aligned");
+  // Every argument check comes BEFORE the first launch: a call that returns LBFA_EINVAL has enqueued nothing (no wasted
+  // work, no stray nodes in a stream capture the caller believes failed).
+  if (dtype != LBFA_F16 && dtype != LBFA_BF16) return fail(LBFA_EINVAL, "Input tensors must be in dtype of float16 or bfloat16");
+  if (q_qmax != 127 && q_qmax != 7) return fail(LBFA_EINVAL, "lbfa_forward: q_qmax must be 127 (int8) or 7 (int4 range), got %d", q_qmax);
+  if (k_qmax != 127 && k_qmax != 7) return fail(LBFA_EINVAL, "lbfa_forward: k_qmax must be 127 (int8) or 7 (int4 range), got %d", k_qmax);
+  if (!aligned16(q) || (strides_q[0] | strides_q[1] | strides_q[2]) % 8 != 0)
+    return fail(LBFA_EINVAL, "lbfa_forward: q must be 16-byte aligned with strides that are multiples of 8 elements");
+  if (!aligned16(k) || (strides_k[0] | strides_k[1] | strides_k[2]) % 8 != 0)
+    return fail(LBFA_EINVAL, "lbfa_forward: k must be 16-byte aligned with strides that are multiples of 8 elements");
+  if (!aligned16(v) || (strides_v[0] | strides_v[1] | strides_v[2]) % 8 != 0)
+    return fail(LBFA_EINVAL, "lbfa_forward: v must be 16-byte aligned with strides that are multiples of 8 elements");
+  if ((reinterpret_cast<uintptr_t>(o) & 7u) || (strides_o[0] | strides_o[1] | strides_o[2]) % 4 != 0)
+    return fail(LBFA_EINVAL, "lbfa_forward: o must be 8-byte aligned with strides that are multiples of 4 elements");
+  if (is_causal && Sq != Sk) return fail(LBFA_EINVAL, "qo_len and kv_len must be equal for causal attention");
+  {
+    const int64_t lim = 0x7fffffffLL;
+    const int64_t vwin = pv_fp8 ? ((int64_t)Sk + 2 * LBFA_BLKK) * D : 2 * (((int64_t)Sk + 2 * LBFA_BLKK) * strides_v[2] + D);
+    if (2 * (((int64_t)Sq + LBFA_BLKQ) * strides_q[2] + D) > lim || ((int64_t)Sk + 2 * LBFA_BLKK) * D + D > lim || vwin > lim)
+      return fail(LBFA_EINVAL, "lbfa_forward: per-(batch,head) operand window exceeds 2 GiB");
+  }
+  if ((int64_t)B * Hq * ((Sq + LBFA_BLKQ - 1) / LBFA_BLKQ) > 0x7fffffffLL) return fail(LBFA_EINVAL, "lbfa_forward: grid too large");
   char* ws = (char*)workspace;
   void* km = smooth_k ? (void*)(ws + L.km) : nullptr;
   int8_t* k8 = (int8_t*)(ws + L.k8);
@@ -347,9 +368,6 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
   }
   // Q is quantised by the attention kernel itself (each workgroup its own 128-row block: same codes and scales as
   // lbfa_quant_per_block, sm_scale * log2(e) folded in, src/triton/quant_per_block.py:226), as is lse_correction = q . km
-  if (q_qmax != 127 && q_qmax != 7) return fail(LBFA_EINVAL, "lbfa_forward: q_qmax must be 127 (int8) or 7 (int4 range), got %d", q_qmax);
-  if (!aligned16(q) || (strides_q[0] | strides_q[1] | strides_q[2]) % 8 != 0)
-    return fail(LBFA_EINVAL, "lbfa_forward: q must be 16-byte aligned with strides that are multiples of 8 elements");
   st = quant_impl(k, dtype, km, 1, k8, ks, 1.0f, k_qmax, LBFA_BLKK, B, Hkv, Sk, D, Dg, strides_k, sk8, nullptr, 1, nullptr, stream);
   if (st) return st;
   const void* v_in = v;
@@ -362,18 +380,7 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
     v_dtype = LBFA_E4M3;
     v_scale = (const float*)(ws + L.vs);
   }
-  // attention (same checks as lbfa_attn_fwd), with the LSE fix-up of src/core.py:344-350 fused into the epilogue
-  if (is_causal && Sq != Sk) return fail(LBFA_EINVAL, "qo_len and kv_len must be equal for causal attention");
-  if (v_dtype != LBFA_E4M3 && (!aligned16(v) || (strides_v[0] | strides_v[1] | strides_v[2]) % 8 != 0))
-    return fail(LBFA_EINVAL, "lbfa_forward: v must be 16-byte aligned with strides that are multiples of 8 elements");
-  if ((reinterpret_cast<uintptr_t>(o) & 7u) || (strides_o[0] | strides_o[1] | strides_o[2]) % 4 != 0)
-    return fail(LBFA_EINVAL, "lbfa_forward: o must be 8-byte aligned with strides that are multiples of 4 elements");
-  {
-    const int64_t lim = 0x7fffffffLL;
-    const int64_t vwin = v_dtype == LBFA_E4M3 ? ((int64_t)Sk + 2 * LBFA_BLKK) * D : 2 * (((int64_t)Sk + 2 * LBFA_BLKK) * strides_v[2] + D);
-    if (2 * (((int64_t)Sq + LBFA_BLKQ) * strides_q[2] + D) > lim || ((int64_t)Sk + 2 * LBFA_BLKK) * D + D > lim || vwin > lim)
-      return fail(LBFA_EINVAL, "lbfa_forward: per-(batch,head) operand window exceeds 2 GiB");
-  }
+  // attention, with the LSE fix-up of src/core.py:344-350 fused into the epilogue
   lbfa::AttnParams p;
   p.q = (const int8_t*)q; p.k = k8; p.v = v_in; p.o = o; p.lse = lse;
   p.q_scale = nullptr; p.k_scale = ks; p.v_scale = v_scale;
@@ -394,7 +401,6 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
   p.q_sm_scale = (float)(sm_scale * 1.44269504);  // ONE rounding of the double product, as the reference's kernel argument
   p.q_qmax = (float)q_qmax;
   p.q_dot_vec = want_corr ? (const unsigned short*)km : nullptr;
-  if ((int64_t)B * Hq * p.nQ > 0x7fffffffLL) return fail(LBFA_EINVAL, "lbfa_forward: grid too large");
   g_err[0] = 0;
   return check_hip(launch_attention(p, D, v_dtype, dtype, is_causal ? 1 : 0, (hipStream_t)stream, true), "lbfa_forward launch");
 }
@@ -560,6 +566,22 @@ int lbfa_forward_varlen(const void* q, const void* k, const void* v, int dtype, 
   const VarlenLayout L = varlen_layout(B, Hq, Hkv, total_q, total_k, max_seqlen_q, max_seqlen_k, D);
   if (workspace_bytes < L.total) return fail(LBFA_EINVAL, "lbfa_forward_varlen: workspace too small (%zu < %zu)", workspace_bytes, L.total);
   if (!aligned16(workspace)) return fail(LBFA_EINVAL, "lbfa_forward_varlen: workspace must be 16-byte aligned");
+  // every argument check before the first launch (see lbfa_forward)
+  if (dtype != LBFA_F16 && dtype != LBFA_BF16) return fail(LBFA_EINVAL, "Input tensors must be in dtype of float16 or bfloat16");
+  if (q_qmax != 127 && q_qmax != 7) return fail(LBFA_EINVAL, "lbfa_forward_varlen: q_qmax must be 127 (int8) or 7 (int4 range), got %d", q_qmax);
+  if (k_qmax != 127 && k_qmax != 7) return fail(LBFA_EINVAL, "lbfa_forward_varlen: k_qmax must be 127 (int8) or 7 (int4 range), got %d", k_qmax);
+  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (reinterpret_cast<uintptr_t>(o) & 7u))
+    return fail(LBFA_EINVAL, "lbfa_forward_varlen: q/k/v must be 16-byte aligned and o 8-byte aligned");
+  if ((strides_q[0] | strides_q[1] | strides_k[0] | strides_k[1] | strides_v[0] | strides_v[1]) % 8 != 0)
+    return fail(LBFA_EINVAL, "lbfa_forward_varlen: q / k / v strides must be multiples of 8 elements");
+  if ((strides_o[0] | strides_o[1]) % 4 != 0) return fail(LBFA_EINVAL, "lbfa_forward_varlen: o strides must be multiples of 4 elements");
+  {
+    const int64_t lim = 0x7fffffffLL;
+    if (2 * (((int64_t)max_seqlen_q + LBFA_BLKQ) * strides_q[1] + D) > lim || ((int64_t)max_seqlen_k + 2 * LBFA_BLKK) * Hkv * D + D > lim ||
+        2 * (((int64_t)max_seqlen_k + 2 * LBFA_BLKK) * strides_v[1] + D) > lim)
+      return fail(LBFA_EINVAL, "lbfa_forward_varlen: per-sequence operand window exceeds 2 GiB (token stride x max_seqlen too large)");
+  }
+  if ((int64_t)B * Hq * ((max_seqlen_q + LBFA_BLKQ - 1) / LBFA_BLKQ) > 0x7fffffffLL) return fail(LBFA_EINVAL, "lbfa_forward_varlen: grid too large");
   char* ws = (char*)workspace;
   void* km = smooth_k ? (void*)(ws + L.km) : nullptr;
   int8_t* k8 = (int8_t*)(ws + L.k8);
@@ -572,7 +594,6 @@ int lbfa_forward_varlen(const void* q, const void* k, const void* v, int dtype, 
     if (st) return st;
   }
   // Q is quantised by the attention kernel itself (blocks restart at every sequence start, as the quantiser's do)
-  if (!aligned16(q)) return fail(LBFA_EINVAL, "lbfa_forward_varlen: q must be 16-byte aligned");
   st = quant_varlen_core("lbfa_forward_varlen (K)", k, dtype, km, 1, k8, ks, cu_seqlens_k, nullptr, 1.0f, k_qmax, LBFA_BLKK, B,
                          max_seqlen_k, Hkv, D, Dg, strides_k, sk8, stream);
   if (st) return st;

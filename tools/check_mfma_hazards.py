@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Static check of the SHIPPED gfx950 code object for the XDL-write -> VALU-read hazard behind the 16-pass block-scaled MFMA.
+
+Background (DESIGN.md 3.1, fp8 PV): `v_mfma_scale_f32_32x32x64_f8f6f4` with e4m3 operands takes 16 passes (64 cycles: twice
+the cycles of the bf16 32x32 form, MI355X_MICROARCH.md, Matrix cores); with fp6 / fp4 operands the same opcode takes 8.  gfx950
+does NOT interlock a VALU / VMEM / LDS / export read of an XDL result: software must leave
+
+        passes + 3 (+ 1 on gfx950 when passes != 2)   = 20 wait states for a 16-pass MFMA before a read,
+        passes + 2 (+ 1 on gfx950)                     = 19 before a VALU overwrite (WAW)
+
+(the rule LLVM's GCNHazardRecognizer implements for gfx940 / gfx950, checkMAIVALUHazards).  ROCm 7.2's clang sizes the gap for
+the opcode's 8-pass form whatever the operand formats: it leaves 8 + 3 + 1 = 12.  The kernel therefore adds `s_nop 7` (8 wait
+states, LBFA_MX_NOP) behind its PV MFMAs: 12 + 8 = 20.  That count is derived, not tuned - and this tool proves it on the
+binary: for EVERY such MFMA it walks EVERY successor path (branches followed both ways, loops included) to the first
+instruction that touches the destination registers and counts the wait states in between (one per instruction issued,
+N + 1 for `s_nop N`; an `s_waitcnt` / `s_barrier` is counted as ONE although it usually lasts far longer).  A touching MFMA
+that accumulates onto the same registers (SrcC = vDst chain) is exempt: back-to-back dependent XDL ops are interlocked.
+
+    python tools/check_mfma_hazards.py [path/to/liblowbit_fa_hip.so]      exit code 1 if any path is short
+"""
+from __future__ import annotations
+
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
+NEED_READ = 20   # 16 passes + 3 + 1
+HORIZON = 32     # stop following a path after this many wait states
+
+_reg = re.compile(r"\b([va])(?:(\d+)|\[(\d+):(\d+)\])")
+_fn = re.compile(r"^([0-9a-f]+) <([^>]+)>:$")
+_ins = re.compile(r"^\t(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):")
+_tgt = re.compile(r"<([^>+]+)(?:\+0x([0-9a-f]+))?>\s*$")
+
+
+def tools_available() -> bool:
+    return all(os.path.exists(os.path.join(LLVM, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump"))
+
+
+def disassemble(so_path: str) -> list[str]:
+    """gfx950 disassembly of every code object bundled in the shared library (one bundle per translation unit)."""
+    out: list[str] = []
+    with tempfile.TemporaryDirectory() as td:
+        fat = os.path.join(td, "fat.bin")
+        subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", so_path, os.path.join(td, "x")], check=True,
+                       capture_output=True)
+        blob = open(fat, "rb").read()
+        pos, i = [], blob.find(MAGIC)
+        while i >= 0:
+            pos.append(i)
+            i = blob.find(MAGIC, i + 1)
+        for n, (a, b) in enumerate(zip(pos, pos[1:] + [len(blob)])):
+            part, co = os.path.join(td, f"p{n}.bin"), os.path.join(td, f"co{n}.o")
+            open(part, "wb").write(blob[a:b])
+            subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={part}", f"--targets={TARGET}",
+                            f"--output={co}"], check=True, capture_output=True)
+            if os.path.getsize(co) == 0:
+                continue
+            r = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--mcpu=gfx950", co], check=True, capture_output=True, text=True)
+            out += r.stdout.splitlines()
+    return out
+
+
+def _regs(text: str) -> set:
+    s = set()
+    for m in _reg.finditer(text):
+        if m.group(2) is not None:
+            s.add((m.group(1), int(m.group(2))))
+        else:
+            s.update((m.group(1), k) for k in range(int(m.group(3)), int(m.group(4)) + 1))
+    return s
+
+
+def parse(lines: list[str]) -> dict:
+    """name -> list of (addr, mnemonic, operand text, branch target addr or None)"""
+    fns, cur, base = {}, None, {}
+    for ln in lines:
+        m = _fn.match(ln)
+        if m:
+            cur = m.group(2)
+            base[cur] = int(m.group(1), 16)
+            fns[cur] = []
+            continue
+        m = _ins.match(ln)
+        if m and cur is not None:
+            mn, ops, addr = m.group(1), m.group(2), int(m.group(3), 16)
+            tgt = None
+            if mn.startswith("s_cbranch") or mn == "s_branch":
+                t = _tgt.search(ln)
+                if t and t.group(1) in base:
+                    tgt = base[t.group(1)] + (int(t.group(2), 16) if t.group(2) else 0)
+            fns[cur].append((addr, mn, ops, tgt))
+    return fns
+
+
+def check_function(ins: list) -> list:
+    """[(mfma addr, min wait states to the first non-exempt touch of its result, touching instruction)] for every scaled MFMA"""
+    index = {a: i for i, (a, _, _, _) in enumerate(ins)}
+    res = []
+    for i, (addr, mn, ops, _) in enumerate(ins):
+        if "mfma_scale" not in mn:
+            continue
+        dst = _regs(ops.split(",")[0])
+        best, best_ins = HORIZON, None
+        seen: dict = {}
+        stack = [(i + 1, 0)]
+        while stack:
+            j, w = stack.pop()
+            while j < len(ins):
+                if w >= HORIZON or seen.get(j, HORIZON + 1) <= w:
+                    break
+                seen[j] = w
+                a2, mn2, ops2, tgt2 = ins[j]
+                if _regs(ops2) & dst:
+                    if mn2.startswith("v_mfma") and _regs(ops2.split(",")[0]) == _regs(ops2.split(",")[3] if ops2.count(",") >= 3 else ""):
+                        pass  # accumulate chain onto the same registers: interlocked; that MFMA is checked on its own
+                    elif w < best:
+                        best, best_ins = w, f"{a2:x}: {mn2} {ops2}"
+                    break
+                if mn2 == "s_endpgm" or mn2.startswith("s_setpc") or mn2.startswith("s_swappc"):
+                    break
+                w += int(ops2.split()[0], 0) + 1 if mn2 == "s_nop" else 1
+                if mn2 == "s_branch":
+                    if tgt2 in index:
+                        j = index[tgt2]
+                        continue
+                    break
+                if mn2.startswith("s_cbranch") and tgt2 in index:
+                    stack.append((index[tgt2], w))
+                j += 1
+        res.append((addr, best, best_ins))
+    return res
+
+
+def check(so_path: str) -> dict:
+    fns = parse(disassemble(so_path))
+    report = {"mfma_scale": 0, "min_wait_states": HORIZON, "short": [], "required": NEED_READ}
+    for name, ins in fns.items():
+        for addr, w, what in check_function(ins):
+            report["mfma_scale"] += 1
+            if w < report["min_wait_states"]:
+                report["min_wait_states"], report["closest"] = w, f"{name} @{addr:x} -> {what}"
+            if w < NEED_READ:
+                report["short"].append((name, hex(addr), w, what))
+    return report
+
+
+if __name__ == "__main__":
+    so = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                            "lowbit_quant_fa2_paddle_amd", "liblowbit_fa_hip.so")
+    rep = check(so)
+    print(f"{rep['mfma_scale']} block-scaled MFMAs; fewest wait states before a dependent non-MFMA access: {rep['min_wait_states']}"
+          f"{'+' if rep['min_wait_states'] >= HORIZON else ''} (required {NEED_READ})")
+    if "closest" in rep and rep["min_wait_states"] < HORIZON:
+        print("closest:", rep["closest"])
+    for s in rep["short"][:20]:
+        print("SHORT:", s)
+    sys.exit(1 if rep["short"] else 0)

@@ -10,6 +10,14 @@ For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank proce
 that size (the op is independent per (batch, head): no data-path collective) - weak scaling.
 Rank 0 prints ONE JSON line.  metric = attention TFLOP/s with the reference's FLOP formula
 4*B*H*D*S*S (halved for causal; utils/benchmark.py:212-214).
+
+Besides `value` (the default workload) the line carries, measured in the same process on the same device:
+  * `sweep` (N = 1): the whole BASELINE metric range - S in {4K, 8K, 16K, 32K} x D in {64, 128} x {non-causal, causal} for
+    qk_int8_pv_fp16 plus C3 / C4 / C4-mixed / the C5 per-GPU shard - whole-operator and attention-kernel TFLOP/s, roofline
+    fraction, torch's flash SDPA and this library's own fp16 kernel on the same inputs (example/draw/draw_single.py:15-21
+    is the reference's version of this table);
+  * `c5_strong` (every N): BASELINE configs[4] itself, qk_int8_pv_fp8 B=32 H32 S32768 D128 split over the N ranks
+    (B = 32 / N each, no data-path collective), and the RCCL all-gather of the output shards for N > 1.
 """
 import argparse
 import json
@@ -50,23 +58,35 @@ def log(*a):
 
 def cpu_baseline(B, H, S, D, causal, budget_s=12.0):
     """Naive SDPA (the repo's `manual_scaled_dot_product_attention`, src/core.py:46-69, restated in
-    oracle/lowbit_fa_oracle.py::sdpa_naive) on the host cores, fp32, on a bounded sample of (b,h) slices of the
-    same workload; the op is independent per slice so throughput extrapolates linearly."""
+    oracle/lowbit_fa_oracle.py) on the host cores, fp32, on a bounded sample of (b,h) slices of the same workload; the op
+    is independent per slice so throughput extrapolates linearly.  Paddle is not installed: torch CPU tensor ops stand in
+    for the reference's Paddle-CPU path, numpy/BLAS if torch's CPU path fails."""
     import numpy as np
     from oracle import lowbit_fa_oracle as orc
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
-    except Exception:
-        threads = len(os.sched_getaffinity(0))
     rng = np.random.default_rng(0)
     q = rng.standard_normal((1, 1, S, D), dtype=np.float32)
     k = rng.standard_normal((1, 1, S, D), dtype=np.float32)
     v = rng.standard_normal((1, 1, S, D), dtype=np.float32)
-    orc.sdpa_naive(q[:, :, :256], k[:, :, :256], v[:, :, :256], is_causal=causal)  # warm BLAS threads
+    impl = "numpy/BLAS (oracle.sdpa_naive)"
+    run = lambda: orc.sdpa_naive(q, k, v, is_causal=causal)
+    threads = len(os.sched_getaffinity(0))
+    try:
+        import torch
+        tq, tk, tv = (torch.from_numpy(a) for a in (q, k, v))
+        orc.sdpa_naive_torch(tq[:, :, :256], tk[:, :, :256], tv[:, :, :256], is_causal=causal)
+        run = lambda: orc.sdpa_naive_torch(tq, tk, tv, is_causal=causal)
+        impl = "torch CPU ops (oracle.sdpa_naive_torch)"
+        threads = int(torch.get_num_threads())
+    except Exception:
+        try:
+            from threadpoolctl import threadpool_info
+            threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+        except Exception:
+            pass
+    run()  # warm the thread pool
     n, t0 = 0, time.perf_counter()
     while True:
-        orc.sdpa_naive(q, k, v, is_causal=causal)
+        run()
         n += 1
         el = time.perf_counter() - t0
         if el >= budget_s or n >= B * H:
@@ -74,7 +94,136 @@ def cpu_baseline(B, H, S, D, causal, budget_s=12.0):
     flops = orc.attention_flops(1, 1, S, S, D, causal) * n
     return {"value": round(flops / el / 1e12, 5), "unit": "TFLOP/s", "cores": int(threads), "kind": "port",
             "sample": f"{n} of {B * H} (batch,head) slices of the workload, fp32 naive SDPA "
-                      f"(oracle.sdpa_naive = src/core.py:46-69 restated, numpy/BLAS), {el:.1f} s"}
+                      f"(src/core.py:46-69 restated, {impl}), {el:.1f} s"}
+
+
+def make_inputs(torch, dev, B, H, Hkv, S, D, layout, seed, dist_kind="normal"):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    shp_q = (B, H, S, D) if layout == "HND" else (B, S, H, D)
+    shp_k = (B, Hkv, S, D) if layout == "HND" else (B, S, Hkv, D)
+    if dist_kind == "normal":
+        q = torch.randn(shp_q, generator=g, device=dev, dtype=torch.float32).half()
+        k = torch.randn(shp_k, generator=g, device=dev, dtype=torch.float32).half()
+    else:
+        q = torch.randint(-100, 100, shp_q, generator=g, device=dev).half()
+        k = torch.randint(-100, 100, shp_k, generator=g, device=dev).half()
+    v = torch.randn(shp_k, generator=g, device=dev, dtype=torch.float32).half()
+    return q, k, v
+
+
+def time_fn(torch, f, iters, warmup=2):
+    for _ in range(warmup):
+        f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        f()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def sweep_point(torch, lb, lib, dev, name, spec, iters, refs=True):
+    """One row of the `sweep` table: whole operator + attention kernel (library-recorded HIP events) + the two fp16
+    comparison points on the same inputs."""
+    api, B, H, Hkv, S, D, layout, causal, extra, desc = spec
+    fn = {"int8_fp16": lb.lowbit_fa_qk_int8_pv_fp16_triton, "int4_fp16": lb.lowbit_fa_qk_int4_pv_fp16_triton,
+          "int8_fp8": lb.lowbit_fa_qk_int8_pv_fp8_cuda}[api]
+    q, k, v = make_inputs(torch, dev, B, H, Hkv, S, D, layout, 99)
+    f = lambda: fn(q, k, v, tensor_layout=layout, is_causal=causal, **extra)
+    flops = 4.0 * B * H * D * S * S / (2 if causal else 1)
+    for _ in range(2):
+        f()
+    evs = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        lib.lbfa_profile_next_attn(e0.cuda_event, e1.cuda_event)
+        f()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    kms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / iters
+    peak = PEAK_I8_TF if api == "int8_fp8" else PEAK_MIX_TF
+    row = {"workload": name, "api": api, "B": B, "H": H, "S": S, "D": D, "layout": layout, "causal": causal,
+           "ms": round(dt * 1e3, 4), "tflops": round(flops / dt / 1e12, 1), "kernel_ms": round(kms, 4),
+           "kernel_tflops": round(flops / (kms * 1e-3) / 1e12, 1), "frac": round(flops / (kms * 1e-3) / 1e12 / peak, 4)}
+    if refs and api != "int8_fp8":
+        try:
+            from torch.nn.attention import sdpa_kernel, SDPBackend
+            qh, kh, vh = (t if layout == "HND" else t.transpose(1, 2) for t in (q, k, v))
+            with sdpa_kernel(SDPBackend.FLASH_ATTENTION):
+                d2 = time_fn(torch, lambda: torch.nn.functional.scaled_dot_product_attention(qh, kh, vh, is_causal=causal), max(3, iters // 2))
+            row["torch_fa2_tflops"] = round(flops / d2 / 1e12, 1)
+            row["vs_torch_fa2"] = round(d2 / dt, 3)
+        except Exception as e:
+            row["torch_fa2_error"] = str(e)[:80]
+        from lowbit_quant_fa2_paddle_amd import core as _core
+        d3 = time_fn(torch, lambda: _core.flash_attn_fp16(q, k, v, tensor_layout=layout, is_causal=causal), max(3, iters // 2))
+        row["own_fp16_tflops"] = round(flops / d3 / 1e12, 1)
+        row["vs_own_fp16"] = round(d3 / dt, 3)
+    del q, k, v
+    return row
+
+
+def run_sweep(torch, lb, lib, dev):
+    rows = []
+    for D in (64, 128):
+        for causal in (False, True):
+            for S in (4096, 8192, 16384, 32768):
+                nm = f"int8_fp16 S{S // 1024}K D{D}{' causal' if causal else ''}"
+                spec = ("int8_fp16", 4, 32, 32, S, D, "HND", causal, {}, nm)
+                rows.append(sweep_point(torch, lb, lib, dev, nm, spec, 6 if S <= 8192 else 3))
+    for nm in ("c3", "c4", "c4m", "c5"):
+        rows.append(sweep_point(torch, lb, lib, dev, nm, WORKLOADS[nm], 3, refs=(nm != "c5")))
+    torch.cuda.empty_cache()
+    return rows
+
+
+def c5_strong(torch, lb, dev, world, rank, distributed, dist, share, steps=3):
+    """BASELINE configs[4]: qk_int8_pv_fp8, B=32 H=32 S=32768 D=128 split over `world` ranks by batch."""
+    Bg, H, S, D = 32, 32, 32768, 128
+    if Bg % world != 0:
+        return None
+    B = Bg // world
+    q, k, v = make_inputs(torch, dev, B, H, H, S, D, "HND", 4321 + rank)
+    f = lambda: lb.lowbit_fa_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout="HND", is_causal=False)
+    o = f()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        o = f()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    el = (time.perf_counter() - t0) / steps
+    if distributed:
+        tt = torch.tensor([el], device="cpu" if share else dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    flops = 4.0 * Bg * H * D * S * S
+    res = {"workload": "qk_int8_pv_fp8 B32 H32 S32768 D128 (BASELINE configs[4]), batch split over the ranks, strong scaling",
+           "B_per_gpu": B, "ms": round(el * 1e3, 3), "tflops_total": round(flops / el / 1e12, 1), "steps": steps}
+    if distributed:
+        from lowbit_quant_fa2_paddle_amd import dist as lbdist
+        lbdist.all_gather_batch(o)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            lbdist.all_gather_batch(o)
+        torch.cuda.synchronize()
+        dist.barrier()
+        res["allgather_ms"] = round((time.perf_counter() - t0) / 2 * 1e3, 3)
+        res["allgather_bytes_per_rank"] = int(o.numel() * o.element_size())
+    del q, k, v, o
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -89,6 +238,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fa2", action="store_true", help="skip the torch flash-attention comparison point")
     ap.add_argument("--gather", action="store_true", help="N>1: also time the RCCL all-gather of the output shards")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the S x D x causal sweep (N = 1) that fills the `sweep` key")
+    ap.add_argument("--no-c5", action="store_true", help="skip the C5 strong-scaling measurement that fills `c5_strong`")
     args = ap.parse_args()
 
     import torch
@@ -121,17 +272,7 @@ def main():
     fn = {"int8_fp16": lb.lowbit_fa_qk_int8_pv_fp16_triton, "int4_fp16": lb.lowbit_fa_qk_int4_pv_fp16_triton,
           "int8_fp8": lb.lowbit_fa_qk_int8_pv_fp8_cuda}[api]
 
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
-    shp_q = (B, H, S, D) if layout == "HND" else (B, S, H, D)
-    shp_k = (B, Hkv, S, D) if layout == "HND" else (B, S, Hkv, D)
-    if args.dist == "normal":
-        q = torch.randn(shp_q, generator=g, device=dev, dtype=torch.float32).half()
-        k = torch.randn(shp_k, generator=g, device=dev, dtype=torch.float32).half()
-    else:
-        q = torch.randint(-100, 100, shp_q, generator=g, device=dev).half()
-        k = torch.randint(-100, 100, shp_k, generator=g, device=dev).half()
-    v = torch.randn(shp_k, generator=g, device=dev, dtype=torch.float32).half()
+    q, k, v = make_inputs(torch, dev, B, H, Hkv, S, D, layout, 1234 + rank, args.dist)
 
     def step():
         return fn(q, k, v, tensor_layout=layout, is_causal=causal, **extra)
@@ -236,6 +377,14 @@ def main():
         cpu = cpu_baseline(B, H, S, D, causal)
     if distributed:
         dist.barrier()
+    del q, k, v, o
+    torch.cuda.empty_cache()
+    sweep = None
+    if rank == 0 and world == 1 and not args.no_sweep and args.workload == "c2":
+        sweep = run_sweep(torch, lb, lib, dev)
+    c5s = None
+    if not args.no_c5 and args.workload == "c2":
+        c5s = c5_strong(torch, lb, dev, world, rank, distributed, dist if distributed else None, share)
 
     if rank == 0:
         out = {
@@ -268,6 +417,10 @@ def main():
         }
         if gather_ms is not None:
             out["config"]["allgather_ms"] = round(gather_ms, 3)
+        if sweep is not None:
+            out["sweep"] = sweep
+        if c5s is not None:
+            out["c5_strong"] = c5s
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()

@@ -73,7 +73,9 @@ class TorchOps:
         return self.torch.nn.functional.pad(self.torch.cumsum(t, dim=0), (1, 0), value=0).to(self.torch.int32)
 
 
-class PaddleOps:  # pragma: no cover - Paddle is absent from the build image; same primitives, untested here
+class PaddleOps:
+    """Same primitives over Paddle tensors.  Paddle is absent from the build image: exercised by
+    tests/test_paddle_adaptor_cpu.py against a stand-in module object, never against a live Paddle."""
     name = "paddle"
 
     def __init__(self):
@@ -108,8 +110,8 @@ class PaddleOps:  # pragma: no cover - Paddle is absent from the build image; sa
         return self.paddle.empty(list(shape), dtype=dtype).to(like.place)
 
     def pad_last(self, t, n):
-        return self.paddle.nn.functional.pad(t, [0, n], data_format="NCHW") if t.ndim != 4 else \
-            self.paddle.concat([t, self.paddle.zeros(list(t.shape[:-1]) + [n], dtype=t.dtype)], axis=-1)
+        # zero columns appended to the last axis, any rank (dense [B,H,S,D] / [B,S,H,D] and packed [T,H,D] tensors alike)
+        return self.paddle.concat([t, self.paddle.zeros(list(t.shape[:-1]) + [n], dtype=t.dtype)], axis=-1)
 
     def stream(self, t):
         return self.paddle.device.current_stream().stream_base.raw_stream
@@ -131,26 +133,25 @@ class PaddleOps:  # pragma: no cover - Paddle is absent from the build image; sa
 
 
 def device2str(type=None, index=None, *, device=None):
-    """PaConvert helper the reference calls before every launch (paddle_utils.py:20-36): normalises a
-    device spec to Paddle's 'gpu:N' / 'cpu' strings.  Same accepted inputs, duck-typed on the place."""
-    type = device if device else type
-    if isinstance(type, int):
-        return f"gpu:{type}"
-    if isinstance(type, str):
-        if "cuda" in type:
-            type = type.replace("cuda", "gpu")
-        if "cpu" in type:
+    """Device spec -> Paddle's 'gpu:N' / 'cpu' string, the call the reference makes before every launch
+    (`paddle.device.set_device(device2str(v.place))`, src/core.py:276; helper of paddle_utils.py).  Accepts what that helper
+    accepts: a device index, a 'cuda[:N]' / 'gpu[:N]' / 'cpu' string (optionally with a separate index), None, or a place
+    object (duck-typed: `is_cpu_place()` / `get_device_id()`); anything else is handed back unchanged."""
+    spec = device if device else type
+    if spec is None:
+        return "cpu"
+    if isinstance(spec, int):
+        return f"gpu:{spec}"
+    if isinstance(spec, str):
+        if "cpu" in spec:
             return "cpu"
-        if index is not None:
-            type = f"{type}:{index}"
-        return type
-    if type is None:
+        name = spec.replace("cuda", "gpu")
+        return name if index is None else f"{name}:{index}"
+    is_cpu = getattr(spec, "is_cpu_place", None)
+    if callable(is_cpu) and is_cpu():
         return "cpu"
-    if hasattr(type, "is_cpu_place") and type.is_cpu_place():
-        return "cpu"
-    if hasattr(type, "get_device_id"):
-        return f"gpu:{type.get_device_id()}"
-    return type
+    dev_id = getattr(spec, "get_device_id", None)
+    return f"gpu:{dev_id()}" if callable(dev_id) else spec
 
 
 _OPS = {}

@@ -72,11 +72,13 @@ def all_gather_batch(o, dim: int = 0, group=None):
 
 
 def _pipelined_batch_gather(fn, qs, ks, vs, tensor_layout, world, group, kwargs):
-    """Batch-sharded run with the gather hidden behind the compute: the local shard is processed one batch element
-    at a time, and each finished element is all-gathered asynchronously (RCCL works on its own stream) while the
-    next element's kernels run.  On the xGMI mesh a direct all-gather moves one peer's piece per link, so a piece of
-    B/world/nb of the output costs 1/nb of the link time and only the last piece is exposed.
-    Needs equal shards; returns the full [B, ...] output in rank-major batch order (= the unsharded order)."""
+    """Batch-sharded run with the gather issued behind the compute: the local shard is processed one batch element at a
+    time, and each finished element is all-gathered asynchronously (RCCL works on its own stream) while the next element's
+    kernels run.  Every element goes through `all_gather_into_tensor` on a contiguous [world, ...] staging slice (no list
+    form: RCCL then needs no flatten / copy-out pass and the stream semantics stay simple); one transposing copy at the
+    end puts the result in rank-major batch order (= the unsharded order).  Needs equal shards.
+    UNMEASURED on hardware so far (no multi-GPU node was available to rounds 1-2): the expectation - on the xGMI mesh a
+    direct all-gather moves one peer's piece per link, so only the last element's gather is exposed - is an expectation."""
     import torch
     import torch.distributed as dist
     nb = qs.shape[0]
@@ -85,11 +87,11 @@ def _pipelined_batch_gather(fn, qs, ks, vs, tensor_layout, world, group, kwargs)
     for i in range(nb):
         o_i = fn(qs[i:i + 1], ks[i:i + 1], vs[i:i + 1], tensor_layout=tensor_layout, **kwargs)
         if out is None:
-            out = torch.empty((world, nb) + tuple(o_i.shape[1:]), dtype=o_i.dtype, device=o_i.device)
-        handles.append(dist.all_gather([out[r, i:i + 1] for r in range(world)], o_i.contiguous(), group=group, async_op=True))
+            out = torch.empty((nb, world) + tuple(o_i.shape[1:]), dtype=o_i.dtype, device=o_i.device)
+        handles.append(dist.all_gather_into_tensor(out[i], o_i.contiguous(), group=group, async_op=True))
     for h in handles:
         h.wait()
-    return out.reshape((world * nb,) + tuple(out.shape[2:]))
+    return out.transpose(0, 1).reshape((world * nb,) + tuple(out.shape[2:]))
 
 
 def sharded_attention(fn: Callable, q, k, v, *, tensor_layout: str = "HND", gather: bool = True, group=None,

@@ -491,6 +491,21 @@ def sdpa_naive(q, k, v, is_causal: bool = False, sm_scale=None, return_lse: bool
     return out
 
 
+def sdpa_naive_torch(q, k, v, is_causal: bool = False, sm_scale=None):
+    """The same `manual_scaled_dot_product_attention` (src/core.py:46-69) written with torch CPU tensor ops - the closest
+    stand-in for the reference's Paddle-CPU path when Paddle is not installed (Paddle-CPU, else
+    torch-CPU, else numpy).  q, k, v: torch CPU tensors [B,H,S,D].  Used for the CPU baseline timing only."""
+    import torch
+    D = q.shape[-1]
+    scale = D ** -0.5 if sm_scale is None else sm_scale
+    scores = torch.matmul(q, k.transpose(-1, -2)) * scale                      # :55 (intended K^T)
+    if is_causal:
+        Sq, Sk = scores.shape[-2], scores.shape[-1]
+        mask = torch.tril(torch.ones((Sq, Sk), dtype=scores.dtype))            # :58-61
+        scores = scores + (1 - mask) * -1e9
+    return torch.matmul(torch.softmax(scores, dim=-1), v)                       # :64, :67
+
+
 def attention_flops(B: int, H: int, Sq: int, Sk: int, D: int, causal: bool) -> float:
     """FLOP formula of the reference's bench harness: 4*B*H*D*S*S, halved for causal
     (utils/benchmark.py:212-214; example/test_sageattn_operator.py:96-98)."""

@@ -4,7 +4,7 @@ tag=${1:-r}
 out=gpurun_out/sweep_$tag.jsonl
 : > $out
 for wl in c2 c2c s8k s16k s32k d128 c3 c4 c4m c5; do
-  timeout -k 10 280 python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline >> $out 2>> gpurun_out/sweep_$tag.err || echo "{\"workload\": \"$wl\", \"failed\": true}" >> $out
+  timeout -k 10 280 python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-sweep --no-c5 >> $out 2>> gpurun_out/sweep_$tag.err || echo "{\"workload\": \"$wl\", \"failed\": true}" >> $out
 done
 python - <<PY
 import json

@@ -132,7 +132,7 @@ def sweep_point(torch, lb, lib, dev, name, spec, iters, refs=True):
     q, k, v = make_inputs(torch, dev, B, H, Hkv, S, D, layout, 99)
     f = lambda: fn(q, k, v, tensor_layout=layout, is_causal=causal, **extra)
     flops = 4.0 * B * H * D * S * S / (2 if causal else 1)
-    for _ in range(2):
+    for _ in range(3):
         f()
     evs = []
     for _ in range(iters):
@@ -176,7 +176,7 @@ def run_sweep(torch, lb, lib, dev):
             for S in (4096, 8192, 16384, 32768):
                 nm = f"int8_fp16 S{S // 1024}K D{D}{' causal' if causal else ''}"
                 spec = ("int8_fp16", 4, 32, 32, S, D, "HND", causal, {}, nm)
-                rows.append(sweep_point(torch, lb, lib, dev, nm, spec, 6 if S <= 8192 else 3))
+                rows.append(sweep_point(torch, lb, lib, dev, nm, spec, {4096: 40, 8192: 16, 16384: 6, 32768: 3}[S]))
     for nm in ("c3", "c4", "c4m", "c5"):
         rows.append(sweep_point(torch, lb, lib, dev, nm, WORKLOADS[nm], 3, refs=(nm != "c5")))
     torch.cuda.empty_cache()

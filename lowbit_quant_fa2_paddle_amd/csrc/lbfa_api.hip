@@ -11,7 +11,7 @@ namespace lbfa {
 int mean_rows_per_split(int S);
 size_t v_fp8_payload_bytes(int B, int H, int S, int D);
 hipError_t launch_mean_seq(const void* x, int dtype, void* out, void* ws, int B, int H, int S, int D, int d_valid,
-                           const int64_t* st, hipStream_t stream);
+                           const int64_t* st, hipStream_t stream, bool finalize);
 hipError_t launch_quant_per_block(const QuantParams& p, int dtype, int D, int blk, hipStream_t stream);
 hipError_t launch_quant_v_fp8(const void* v, int dtype, uint8_t* out, float* v_scale, int B, int H, int S, int D,
                               int d_valid, const int64_t* st, hipStream_t stream);
@@ -89,7 +89,7 @@ size_t lbfa_mean_seq_workspace_bytes(int B, int H, int S, int D) {
 
 namespace {
 int mean_impl(const void* x, int dtype, void* mean_out, void* workspace, size_t workspace_bytes,
-              int B, int H, int S, int D, int d_valid, const int64_t strides_x[3], void* stream) {
+              int B, int H, int S, int D, int d_valid, const int64_t strides_x[3], void* stream, bool finalize = true) {
   if (!x || !mean_out || !workspace || !strides_x) return fail(LBFA_EINVAL, "lbfa_mean_seq: null pointer");
   if (!dims_ok(B, H, S, D)) return fail(LBFA_EINVAL, "Unsupported head_dim: %d (or empty tensor %dx%dx%d)", D, B, H, S);
   if (dtype != LBFA_F16 && dtype != LBFA_BF16)
@@ -98,7 +98,7 @@ int mean_impl(const void* x, int dtype, void* mean_out, void* workspace, size_t 
   if (!aligned16(x) || (strides_x[0] | strides_x[1] | strides_x[2]) % 8 != 0)
     return fail(LBFA_EINVAL, "lbfa_mean_seq: x must be 16-byte aligned with strides that are multiples of 8 elements");
   g_err[0] = 0;
-  return check_hip(lbfa::launch_mean_seq(x, dtype, mean_out, workspace, B, H, S, D, d_valid, strides_x, (hipStream_t)stream),
+  return check_hip(lbfa::launch_mean_seq(x, dtype, mean_out, workspace, B, H, S, D, d_valid, strides_x, (hipStream_t)stream, finalize),
                    "lbfa_mean_seq launch");
 }
 }  // namespace
@@ -112,7 +112,8 @@ namespace {
 int quant_impl(const void* x, int dtype, const void* mean, int mean_group, int8_t* out, float* scale,
                float sm_scale, int qmax, int blk, int B, int H, int S, int D, int d_valid,
                const int64_t strides_x[3], const int64_t strides_out[3],
-               const void* rowdot_vec, int rowdot_group, float* rowdot_out, void* stream) {
+               const void* rowdot_vec, int rowdot_group, float* rowdot_out, void* stream,
+               const double* mean_partial = nullptr, int mean_nsplit = 0) {
   if (!x || !out || !scale || !strides_x || !strides_out) return fail(LBFA_EINVAL, "lbfa_quant_per_block: null pointer");
   if (!dims_ok(B, H, S, D)) return fail(LBFA_EINVAL, "Unsupported head_dim: %d (or empty tensor %dx%dx%d)", D, B, H, S);
   if (dtype != LBFA_F16 && dtype != LBFA_BF16)
@@ -144,6 +145,11 @@ int quant_impl(const void* x, int dtype, const void* mean, int mean_group, int8_
   p.scale_b = (int64_t)H * p.nblk; p.scale_h = p.nblk; p.scale_blk = 1;
   p.cu_seqlens = nullptr; p.cu_scale = nullptr; p.mean_b = 1;
   p.d_valid = d_valid;
+  // fused last step of the mean: `mean` is then the OUTPUT buffer km is stored to
+  p.mean_partial = mean ? mean_partial : nullptr;
+  p.mean_out = mean_partial ? (unsigned short*)const_cast<void*>(mean) : nullptr;
+  p.mean_nsplit = mean_nsplit;
+  p.mean_S = S;
   g_err[0] = 0;
   return check_hip(lbfa::launch_quant_per_block(p, dtype, D, blk, (hipStream_t)stream), "lbfa_quant_per_block launch");
 }
@@ -193,6 +199,7 @@ int quant_varlen_core(const char* who, const void* x, int dtype, const void* mea
   else { p.scale_b = (int64_t)H * p.nblk; p.scale_h = p.nblk; p.scale_blk = 1; }  // [B, H, max_blocks]
   p.cu_seqlens = cu_seqlens; p.cu_scale = cu_scale; p.mean_b = 0;
   p.d_valid = d_valid;
+  p.mean_partial = nullptr; p.mean_out = nullptr; p.mean_nsplit = 0; p.mean_S = 0;
   g_err[0] = 0;
   return check_hip(lbfa::launch_quant_per_block(p, dtype, D, blk, (hipStream_t)stream), who);
 }
@@ -362,13 +369,20 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
   float* ks = (float*)(ws + L.ks);
   const int64_t sk8[3] = {(int64_t)Hkv * Sk * D, (int64_t)Sk * D, D};
   int st;
+  // smooth-K mean: fp64 partial sums per 256 / 1024 rows, and - while there are few of them - no separate finalize launch:
+  // the K quantiser's workgroups add the partials of their (batch, head) themselves (same order, same roundings) and
+  // store km for the LSE correction.  (mean_finalize alone is 6.6 us of pure launch latency at C2.)
+  const int nsplit = (Sk + lbfa::mean_rows_per_split(Sk) - 1) / lbfa::mean_rows_per_split(Sk);
+  const bool fuse_finalize = smooth_k && nsplit <= 64;
   if (smooth_k) {
-    st = mean_impl(k, dtype, km, ws + L.part, lbfa_mean_seq_workspace_bytes(B, Hkv, Sk, D), B, Hkv, Sk, D, Dg, strides_k, stream);
+    st = mean_impl(k, dtype, km, ws + L.part, lbfa_mean_seq_workspace_bytes(B, Hkv, Sk, D), B, Hkv, Sk, D, Dg, strides_k, stream,
+                   !fuse_finalize);
     if (st) return st;
   }
   // Q is quantised by the attention kernel itself (each workgroup its own 128-row block: same codes and scales as
   // lbfa_quant_per_block, sm_scale * log2(e) folded in, src/triton/quant_per_block.py:226), as is lse_correction = q . km
-  st = quant_impl(k, dtype, km, 1, k8, ks, 1.0f, k_qmax, LBFA_BLKK, B, Hkv, Sk, D, Dg, strides_k, sk8, nullptr, 1, nullptr, stream);
+  st = quant_impl(k, dtype, km, 1, k8, ks, 1.0f, k_qmax, LBFA_BLKK, B, Hkv, Sk, D, Dg, strides_k, sk8, nullptr, 1, nullptr, stream,
+                  fuse_finalize ? (const double*)(ws + L.part) : nullptr, nsplit);
   if (st) return st;
   const void* v_in = v;
   int v_dtype = dtype;

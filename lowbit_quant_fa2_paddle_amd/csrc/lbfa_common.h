@@ -106,6 +106,12 @@ struct QuantParams {
   const int* cu_scale;
   int d_valid;  // columns >= d_valid of x are padding: not read, codes 0 (head-dim pad of src/core.py:277-287 without a copy)
   int mean_b;  // 1: mean / rowdot_vec are per batch entry; 0: one vector set shared by all (varlen k.mean(dim=0), :453)
+  // Fused last step of the mean (lbfa_forward): instead of reading `mean`, every workgroup adds the fp64 partial sums of its
+  // (batch, head) itself - [.., mean_nsplit, D] doubles written by mean_partial_kernel, same order and roundings as
+  // mean_finalize_kernel - and the workgroup of block 0 stores the result to `mean_out` (for the LSE correction q . km).
+  const double* mean_partial;  // null: read `mean`
+  unsigned short* mean_out;    // may be null
+  int mean_nsplit, mean_S;
 };
 
 struct AttnParams {

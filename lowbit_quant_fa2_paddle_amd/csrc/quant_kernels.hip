@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void quant_per_block_kernel(QuantParams p) {
   constexpr int RPP = 256 / CPR;  // rows per pass
   constexpr int NP = BLK / RPP;   // passes
   __shared__ float wmax[4];
+  __shared__ float smean[D];
   const int blk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int t = threadIdx.x, c = t % CPR, rl = t / CPR;
   int S = p.S;
@@ -118,8 +119,11 @@ __global__ __launch_bounds__(256) void quant_per_block_kernel(QuantParams p) {
   const int vb = b * p.mean_b;  // which mean / rowdot vector set
 
   float mean[8], vec[8];
-  if constexpr (HAS_MEAN)
-    unpack8<DT>(*reinterpret_cast<const uint4*>(p.mean + ((int64_t)vb * (p.H / p.mean_group) + h / p.mean_group) * D + c * 8), mean);
+  const bool fused_mean = HAS_MEAN && p.mean_partial != nullptr;  // kernel-uniform
+  if constexpr (HAS_MEAN) {
+    if (!fused_mean)
+      unpack8<DT>(*reinterpret_cast<const uint4*>(p.mean + ((int64_t)vb * (p.H / p.mean_group) + h / p.mean_group) * D + c * 8), mean);
+  }
   if constexpr (HAS_DOT)
     unpack8<DT>(*reinterpret_cast<const uint4*>(p.rowdot_vec + ((int64_t)vb * (p.H / p.rowdot_group) + h / p.rowdot_group) * D + c * 8), vec);
 
@@ -130,6 +134,29 @@ __global__ __launch_bounds__(256) void quant_per_block_kernel(QuantParams p) {
     const int row = blk * BLK + ps * RPP + rl;
     raw[ps] = make_uint4(0, 0, 0, 0);  // masked rows load as 0 (quant_per_block.py:170)
     if (row < S && c * 8 < p.d_valid) raw[ps] = *reinterpret_cast<const uint4*>(xbase + (int64_t)row * p.xs);
+  }
+  if constexpr (HAS_MEAN) {
+    if (fused_mean) {  // last step of the mean, while the block's rows are in flight: one lane per channel
+      if (t < D) {
+        const int64_t bh = (int64_t)vb * (p.H / p.mean_group) + h / p.mean_group;
+        const double* src = p.mean_partial + bh * p.mean_nsplit * D + t;
+        double s = 0.0;  // loads issued 16 at a time, added in split order: exactly mean_finalize_kernel
+        for (int i0 = 0; i0 < p.mean_nsplit; i0 += 16) {
+          double v[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) v[j] = (i0 + j < p.mean_nsplit) ? src[(int64_t)(i0 + j) * D] : 0.0;
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (i0 + j < p.mean_nsplit) s += v[j];
+        }
+        const unsigned short km = store_cvt<DT>((float)(s / (double)p.mean_S));
+        smean[t] = load_cvt<DT>(km);
+        if (blk == 0 && p.mean_out != nullptr) p.mean_out[bh * D + t] = km;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mean[i] = smean[c * 8 + i];
+    }
   }
   float xs[NP][8];
   float amax = 0.f;
@@ -324,8 +351,10 @@ namespace lbfa {
 
 int mean_rows_per_split(int S) { return S <= 16384 ? 256 : 1024; }
 
+// finalize = false: only the fp64 partial sums are produced (ws: [B,H,nsplit,D]); the caller's quantiser adds them up
+// itself (QuantParams::mean_partial)
 hipError_t launch_mean_seq(const void* x, int dtype, void* out, void* ws, int B, int H, int S, int D, int d_valid,
-                           const int64_t* st, hipStream_t stream) {
+                           const int64_t* st, hipStream_t stream, bool finalize) {
   MeanParams p;
   p.d_valid = d_valid;
   p.x = (const unsigned short*)x;
@@ -340,6 +369,7 @@ hipError_t launch_mean_seq(const void* x, int dtype, void* out, void* ws, int B,
   if (dtype == LBFA_F16) { if (D == 64) LBFA_MEAN(LBFA_F16, 64); else LBFA_MEAN(LBFA_F16, 128); }
   else { if (D == 64) LBFA_MEAN(LBFA_BF16, 64); else LBFA_MEAN(LBFA_BF16, 128); }
 #undef LBFA_MEAN
+  if (!finalize) return hipGetLastError();
   const int64_t n = (int64_t)B * H * D;
   dim3 g2((unsigned)((n + 255) / 256));
   if (dtype == LBFA_F16) hipLaunchKernelGGL((mean_finalize_kernel<LBFA_F16>), g2, dim3(256), 0, stream, p);

@@ -44,11 +44,16 @@ namespace lbfa {
 #ifndef LBFA_LSUM
 #define LBFA_LSUM(D) ((D) == 64 ? 2 : 0)
 #endif
-// 1: exponentiate / PV per 32-key block with the PV MFMAs of block 0 pinned between the exponentials of block 1
-// (sched_group_barrier).  +1 % at D = 64, -3 % at D = 128.
-#ifndef LBFA_ILV
-#define LBFA_ILV(D) ((D) == 64 ? 1 : 0)
+// Interleave inside the tile (sched_group_barrier): 0 = one long VALU phase, then the PV MFMAs under s_setprio; 1 = the PV
+// MFMAs of the first 32-key block pinned between the exponentials of the second; 2 = per 16-key k-step (PV of step r - 1
+// between the exponentials of step r).  Measured against 0 / 1: D = 64 +4 % / +1 % for 2; D = 128 -1..-3 % for 1 and 2.
+#ifndef LBFA_ILV64
+#define LBFA_ILV64 2
 #endif
+#ifndef LBFA_ILV128
+#define LBFA_ILV128 0
+#endif
+#define LBFA_ILV(D) ((D) == 64 ? LBFA_ILV64 : LBFA_ILV128)
 #ifndef LBFA_DMA
 #define LBFA_DMA 1  // K / V tiles by LDS-DMA (buffer_load ... lds) instead of staging registers + ds_write: +3..5 %
 #endif
@@ -583,9 +588,48 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
     if constexpr (EXACT) update_reference(THR);
     float c1 = c0 - m_run;  // exact (grid argument above); +inf while m_run = -inf
     if constexpr (FP8) c1 += kFp8Offset;
-    exponentiate(std::integral_constant<int, 0>{}, c1);
     constexpr bool ILV = (LBFA_ILV(D) != 0) && !FP8;
-    if constexpr (ILV) {
+    if constexpr (ILV && LBFA_ILV(D) == 2) {
+      // per k-step (16 keys): the PV MFMAs of step r - 1 between the exponentials of step r; only one step's MFMAs are left
+      // without VALU cover at the end of the tile
+      auto exp_q = [&](auto ks_tag) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ks_tag)::value, kb2 = ks >> 1, rb = 8 * (ks & 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          x[kb2][rb + e] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kb2][rb + e], sc, c1));
+          if constexpr (!MSUM) psum += x[kb2][rb + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[ks][e] = (_Float16)x[kb2][rb + e];
+      };
+      auto pv_q = [&](auto ks_tag) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ks_tag)::value;
+        static_for<0, DB>([&](auto i) {
+          constexpr int db = decltype(i)::value;
+          const f16x4 vlo = lds_read_tr16(vbuf + vf_base[db] + ks * 32 * D);
+          const f16x4 vhi = lds_read_tr16(vbuf + vf_base[db] + ks * 32 * D + 16 * D);
+          const f16x8 vf = f16x8{vlo[0], vlo[1], vlo[2], vlo[3], vhi[0], vhi[1], vhi[2], vhi[3]};
+          acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ks], acc_o[db], 0, 0, 0);
+          if constexpr (MSUM && db == DB - 1) rowsum_mfma(l_acc, pf[ks]);
+        });
+      };
+      exp_q(std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<1, 4>([&](auto r) {
+        constexpr int ks = decltype(r)::value;
+        pv_q(std::integral_constant<int, ks - 1>{});
+        exp_q(std::integral_constant<int, ks>{});
+        constexpr int NM = DB + (MSUM ? 2 : 0);
+        constexpr int NV = (MSUM ? 20 : 28) / NM;
+        static_for<0, NM>([&](auto) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      pv_q(std::integral_constant<int, 3>{});
+    } else if constexpr (ILV) {
+      exponentiate(std::integral_constant<int, 0>{}, c1);
       // One wave issues in order: back-to-back MFMAs hold its issue slot and overlap nothing of its own.  Pin the PV MFMAs
       // of block 0 BETWEEN the exponentials of block 1 (one MFMA per few VALU instructions: each MFMA runs in the shadow of
       // the VALU work that follows it).
@@ -603,6 +647,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
     } else {
       // one long VALU phase, then one long MFMA phase under s_setprio: at D = 128 measured faster than two half-tile
       // rounds (the other wave of the SIMD exponentiates in the shadow of this wave's MFMAs)
+      exponentiate(std::integral_constant<int, 0>{}, c1);
       exponentiate(std::integral_constant<int, 1>{}, c1);
       __builtin_amdgcn_sched_barrier(0);  // phase fence: keeps V fragment reads and row-sum adds where they are (registers)
       if constexpr (PRIO & 2) __builtin_amdgcn_s_setprio(1);

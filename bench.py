@@ -171,6 +171,9 @@ def sweep_point(torch, lb, lib, dev, name, spec, iters, refs=True):
 
 def run_sweep(torch, lb, lib, dev):
     rows = []
+    # one throw-away point first: library / allocator / flash-backend initialisation must not land in the first row
+    sweep_point(torch, lb, lib, dev, "warm-up", ("int8_fp16", 1, 8, 8, 2048, 64, "HND", False, {}, "warm-up"), 3)
+    sweep_point(torch, lb, lib, dev, "warm-up", ("int8_fp16", 1, 8, 8, 2048, 128, "HND", True, {}, "warm-up"), 3)
     for D in (64, 128):
         for causal in (False, True):
             for S in (4096, 8192, 16384, 32768):

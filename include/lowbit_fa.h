@@ -17,7 +17,11 @@
  *     the last (head_dim) stride must be 1 (src/core.py:288-290);
  *   - every call only enqueues work on `stream` (a hipStream_t passed as void*; NULL = default
  *     stream, which is where the reference launches, qk_int_sv_f8_cuda.cu:845); no host sync;
- *   - no global mutable state: safe to call concurrently on different devices / streams;
+ *   - no process-global mutable state: safe to call concurrently on different devices / streams.  The only state the
+ *     library keeps is per calling THREAD: the last error message and the one-shot event pair of
+ *     lbfa_profile_next_attn (armed and consumed by the same thread);
+ *   - the one-call entry points (lbfa_forward, lbfa_forward_varlen) validate every argument before their first launch: a
+ *     call that returns LBFA_EINVAL has enqueued nothing (safe under stream capture);
  *   - return 0 on success, non-zero LBFA_E* on failure; `lbfa_last_error()` returns a thread-local
  *     message (the reference raises through TORCH_CHECK, csrc/utils.cuh:19-37, and
  *     std::invalid_argument for unsupported head_dim/flags, csrc/dispatch_utils.h:23-34).
@@ -179,6 +183,8 @@ int lbfa_sdpa_fwd(const void* q, const void* k, const void* v, int dtype, void* 
  * Packed variable-length batches (reference: `sageattn_varlen`, src/core.py:356-491).
  *   q [total_q, Hq, D], k / v [total_k, Hkv, D]; sequence b owns tokens [cu_seqlens[b], cu_seqlens[b+1]);
  *   cu_seqlens_* are int32 device arrays of B + 1 entries; strides are in elements {head, token}.
+ *   max_seqlen_* must be UPPER BOUNDS of the sequence lengths (they size the grids and the padded scale rows, as in the
+ *   reference); a sequence longer than the stated maximum is cut there and nothing is read outside the sized buffers.
  *   Quantisation blocks (128 query / 64 key rows) restart at the start of every sequence.
  *
  * lbfa_quant_per_block_varlen replaces one launch of the varlen `quant_per_block_int8_kernel`

@@ -54,6 +54,13 @@ namespace lbfa {
 #define LBFA_ILV128 0
 #endif
 #define LBFA_ILV(D) ((D) == 64 ? LBFA_ILV64 : LBFA_ILV128)
+// Non-causal: every other ROUND of Q blocks of a head (a round = the workgroups one XCD runs at a time) walks the key tiles
+// from the last one down.  The K + V panel of a head (6..8 MB at S = 16K..32K) does not fit the XCD's 4 MB L2, so every round
+// streams it again; walking back, a round starts on the tiles the previous round has just left in the L2.  The direction
+// depends on the Q block index only (not on what else is in the launch): results do not depend on the batch composition.
+#ifndef LBFA_PINGPONG
+#define LBFA_PINGPONG 1
+#endif
 #ifndef LBFA_DMA
 #define LBFA_DMA 1  // K / V tiles by LDS-DMA (buffer_load ... lds) instead of staging registers + ds_write: +3..5 %
 #endif
@@ -208,10 +215,11 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
   // fetch tile j (into LDS buffer `buf_tag` with DMA, into the staging registers otherwise)
   auto load_tile = [&](int j, auto buf_tag) __attribute__((always_inline)) {  // rows / tiles past the end are outside the descriptor and read as zeros
     constexpr int BUF = decltype(buf_tag)::value;
-    const int ko = j * k_stride32, vo = j * v_stride32;
-    const int k_rem = j < nK ? max(0, k_bytes32 - ko) : 0, v_rem = j < nK ? max(0, v_bytes32 - vo) : 0;
-    const __amdgpu_buffer_rsrc_t k_rs = make_rsrc(kbase + (j < nK ? ko : 0), (unsigned)k_rem);
-    const __amdgpu_buffer_rsrc_t v_rs = make_rsrc(vbase + (j < nK ? vo : 0), (unsigned)v_rem);
+    const bool in_range = (unsigned)j < (unsigned)nK;  // the look-ahead past either end gets a window of 0 bytes
+    const int ko = in_range ? j * k_stride32 : 0, vo = in_range ? j * v_stride32 : 0;
+    const int k_rem = in_range ? max(0, k_bytes32 - ko) : 0, v_rem = in_range ? max(0, v_bytes32 - vo) : 0;
+    const __amdgpu_buffer_rsrc_t k_rs = make_rsrc(kbase + ko, (unsigned)k_rem);
+    const __amdgpu_buffer_rsrc_t v_rs = make_rsrc(vbase + vo, (unsigned)v_rem);
     // DMA destination = wave-uniform base (+ 16 bytes per lane, implicit)
     if constexpr (DMA) {
       char* kdst = smem + BUF * KBYTES + wave * 1024;
@@ -251,7 +259,11 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
     }
   };
 
-  load_tile(0, std::integral_constant<int, 0>{});  // first K / V tile: in flight while Q is fetched (and quantised)
+  // processing order of the key tiles: i-th tile processed = tile_of(i)
+  constexpr int kRound = (D == 64 && !FP8) ? 96 : 64;  // workgroups an XCD runs at a time (32 CUs x 3 or 2)
+  const bool rev = !CAUSAL && (LBFA_PINGPONG != 0) && ((Sk & 63) == 0) && (((qt / kRound) & 1) != 0);  // workgroup-uniform
+  auto tile_of = [&](int i) __attribute__((always_inline)) { return rev ? nK - 1 - i : i; };
+  load_tile(tile_of(0), std::integral_constant<int, 0>{});  // first K / V tile: in flight while Q is fetched (and quantised)
   // ... and so are the dequantisation scales of the first 64 key tiles (lane l: tile l), needed right after the Q prologue
   const float* ksc = nullptr;
   if constexpr (!QK16) ksc = p.k_scale + ksc_base + (int64_t)hk * p.ksc_h;
@@ -692,23 +704,24 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
   using B1 = std::integral_constant<int, 1>;
   using No = std::false_type;
   using Yes = std::true_type;
-  auto step = [&](auto buf_tag, auto nbuf_tag, int j, auto masked_tag, auto exact_tag) __attribute__((always_inline)) {
-    if ((j & 63) == 0 && j != 0) refresh_scale_table(j);  // wave-uniform, once per 64 tiles
-    load_tile(j + 1, nbuf_tag);
+  auto step = [&](auto buf_tag, auto nbuf_tag, int i, auto masked_tag, auto exact_tag) __attribute__((always_inline)) {
+    const int j = tile_of(i);
+    if (i != 0 && (j & 63) == (rev ? 63 : 0)) refresh_scale_table(j & ~63);  // wave-uniform: entering the next chunk of 64 tiles
+    load_tile(tile_of(i + 1), nbuf_tag);
     bool skip = false;
     if constexpr (decltype(masked_tag)::value && CAUSAL) skip = j * 64 > row0 + 31;  // all keys above all rows of this wave
     if (!skip) compute_tile(buf_tag, j, masked_tag, exact_tag, No{});
     store_tile(nbuf_tag);
     __syncthreads();  // with LDS-DMA in flight this waits vmcnt(0) first: tile j + 1 has landed when the barrier opens
   };
-  // All tiles of this Q block.  Tile 0 is in flight (load_tile(0)) or being re-fetched on entry.
+  // All tiles of this Q block, in processing order (tile_of).  The first one is in flight or being re-fetched on entry.
   auto run_tiles = [&](auto exact_tag) __attribute__((always_inline)) {
     constexpr bool EX = decltype(exact_tag)::value || FP8;
-    refresh_scale_table(0);
+    refresh_scale_table(tile_of(0) & ~63);
     store_tile(B0{});
     __syncthreads();
     if constexpr (!EX) {
-      if (n_main > 0) compute_tile(B0{}, 0, No{}, No{}, Yes{});  // reference <- exact row max of the first tile
+      if (n_main > 0) compute_tile(B0{}, tile_of(0), No{}, No{}, Yes{});  // reference <- exact row max of the first tile
     }
     int j = 0;
     for (; j + 1 < n_main; j += 2) {
@@ -753,7 +766,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane(any_bad)) {
       reset_state();
-      load_tile(0, B0{});
+      load_tile(tile_of(0), B0{});
       run_tiles(Yes{});
       row_sum();
     }

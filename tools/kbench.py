@@ -19,6 +19,8 @@ CFG = {  # B,H,S,D,layout,causal,pv
     "c2c": (4, 32, 4096, 64, "HND", True, "fp16"),
     "s16k": (4, 32, 16384, 64, "HND", False, "fp16"),
     "d128": (4, 32, 4096, 128, "HND", False, "fp16"),
+    "s32k": (4, 32, 32768, 64, "HND", False, "fp16"),
+    "c5s": (4, 32, 32768, 128, "HND", False, "fp8"),
     "c3": (4, 32, 16384, 128, "NHD", True, "fp16"),
     "c5": (2, 32, 32768, 128, "HND", False, "fp8"),
     "f8d64": (4, 32, 4096, 64, "HND", False, "fp8"),

@@ -158,3 +158,25 @@ def test_p_to_e4m3_conversion_bit_exact(oracle, dev):
     # saturation, not NaN / inf, beyond the format's range (P is never above 448, V * 448 / amax neither; the convert is
     # still required to clamp): checked on the instruction's documented behaviour through 448 itself above
     assert want[np.argmax(ramp == 448.0)] == 0x7E
+
+
+@pytest.mark.parametrize("D,S,first_rev_row", [(64, 13312, 12288), (128, 8448, 8192)])
+@pytest.mark.parametrize("variant", ["fp16", "fp8"])
+def test_reversed_rounds_of_q_blocks_vs_oracle(oracle, dev, D, S, first_rev_row, variant):
+    """Non-causal kernels walk the key tiles backwards for every other ROUND of Q blocks of a head (ping-pong order for L2
+    reuse, attn_fwd.hip `tile_of`): Q blocks >= 96 (D = 64) / >= 64 (D = 128).  The rows of the first reversed round - with
+    more than 64 key tiles, so the per-64-tile scale table is refreshed downwards too - against the oracle, and a forward
+    block next to them for contrast.  (fp8 at D = 64 keeps 64-block rounds.)"""
+    import lowbit_quant_fa2_paddle_amd as lb
+    q, k, v = oracle.make_inputs(1, 1, S, D, seed=23, k_bias=0.3)
+    tq, tk, tv = (_t(x, "fp16", dev) for x in (q, k, v))
+    fn = lb.lowbit_fa_qk_int8_pv_fp16_triton if variant == "fp16" else lb.lowbit_fa_qk_int8_pv_fp8_cuda
+    o, lse = fn(tq, tk, tv, return_lse=True)
+    assert torch.isfinite(o).all()
+    lo = first_rev_row - 128 if not (variant == "fp8" and D == 64) else 8192 - 128
+    rows = slice(lo, min(lo + 640, S))  # one forward block + the first reversed ones (whole 128-row quantisation blocks)
+    ref, lse_ref = oracle.lowbit_fa_forward(q[:, :, rows], k, v, return_lse=True, amax_floor=1e-7,
+                                            pv="fp8" if variant == "fp8" else "fp16")
+    tol = dict(atol=2e-3, rtol=2e-3) if variant == "fp16" else dict(atol=1e-2, rtol=2e-2)
+    _o_close(_np(o)[:, :, rows], ref, **tol)
+    assert np.abs(lse.cpu().numpy()[:, :, rows] - lse_ref).max() <= (1e-3 if variant == "fp16" else 2e-3) + 2.0 ** -9 * np.abs(lse_ref).max()

@@ -627,6 +627,10 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
       };
       exp_q(std::integral_constant<int, 0>{});
       __builtin_amdgcn_sched_barrier(0);
+#ifndef LBFA_ILV_PRIO
+#define LBFA_ILV_PRIO 2  // s_setprio(1) from here to the end of the tile: +1.6 % at S = 16K (1 = only the last k-step's MFMAs: +0.4 %)
+#endif
+      if constexpr (LBFA_ILV_PRIO == 2) __builtin_amdgcn_s_setprio(1);
       static_for<1, 4>([&](auto r) {
         constexpr int ks = decltype(r)::value;
         pv_q(std::integral_constant<int, ks - 1>{});
@@ -639,6 +643,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
         });
         __builtin_amdgcn_sched_barrier(0);
       });
+      if constexpr (LBFA_ILV_PRIO == 1) __builtin_amdgcn_s_setprio(1);
       pv_q(std::integral_constant<int, 3>{});
     } else if constexpr (ILV) {
       exponentiate(std::integral_constant<int, 0>{}, c1);

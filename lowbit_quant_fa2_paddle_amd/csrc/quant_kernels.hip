@@ -105,21 +105,23 @@ __device__ __forceinline__ void unpack8(const uint4& raw, float (&v)[8]) {
   }
 }
 
-template <int DT, int D, int BLK, bool HAS_MEAN, bool HAS_DOT>
+// NB = consecutive blocks of BLK rows handled by one workgroup (all their rows are requested before any arithmetic; the
+// mean / dot vectors and the fused last step of the mean are fetched once for all of them).
+template <int DT, int D, int BLK, bool HAS_MEAN, bool HAS_DOT, int NB = 1>
 __global__ __launch_bounds__(256) void quant_per_block_kernel(QuantParams p) {
   constexpr int CPR = D / 8;
   constexpr int RPP = 256 / CPR;  // rows per pass
-  constexpr int NP = BLK / RPP;   // passes
-  __shared__ float wmax[4];
+  constexpr int NP = BLK / RPP;   // passes per block
+  __shared__ float wmax[NB][4];
   __shared__ float smean[D];
-  const int blk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int blk0 = blockIdx.x * NB, h = blockIdx.y, b = blockIdx.z;
   const int t = threadIdx.x, c = t % CPR, rl = t / CPR;
   int S = p.S;
   int64_t xoff = (int64_t)b * p.xb, ooff = (int64_t)b * p.ob, sbase = (int64_t)b * p.scale_b;
   if (p.cu_seqlens != nullptr) {  // packed batch: sequence b (quant_per_block_varlen.py:41-48)
     const int s0 = p.cu_seqlens[b];
     S = p.cu_seqlens[b + 1] - s0;
-    if (blk * BLK >= S) return;
+    if (blk0 * BLK >= S) return;
     xoff = (int64_t)s0 * p.xs;
     ooff = (int64_t)s0 * p.os;
     if (p.cu_scale != nullptr) sbase = (int64_t)p.cu_scale[b] * p.scale_b;
@@ -137,16 +139,18 @@ __global__ __launch_bounds__(256) void quant_per_block_kernel(QuantParams p) {
   if constexpr (HAS_DOT)
     unpack8<DT>(*reinterpret_cast<const uint4*>(p.rowdot_vec + ((int64_t)vb * (p.H / p.rowdot_group) + h / p.rowdot_group) * D + c * 8), vec);
 
-  // all loads of the block first (NP independent 16-byte loads in flight per lane), then the arithmetic
-  uint4 raw[NP];
+  // all loads first (NB * NP independent 16-byte loads in flight per lane), then the arithmetic
+  uint4 raw[NB][NP];
 #pragma unroll
-  for (int ps = 0; ps < NP; ++ps) {
-    const int row = blk * BLK + ps * RPP + rl;
-    raw[ps] = make_uint4(0, 0, 0, 0);  // masked rows load as 0 (quant_per_block.py:170)
-    if (row < S && c * 8 < p.d_valid) raw[ps] = *reinterpret_cast<const uint4*>(xbase + (int64_t)row * p.xs);
-  }
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const int row = (blk0 + nb) * BLK + ps * RPP + rl;
+      raw[nb][ps] = make_uint4(0, 0, 0, 0);  // masked rows load as 0 (quant_per_block.py:170)
+      if (row < S && c * 8 < p.d_valid) raw[nb][ps] = *reinterpret_cast<const uint4*>(xbase + (int64_t)row * p.xs);
+    }
   if constexpr (HAS_MEAN) {
-    if (fused_mean) {  // last step of the mean, while the block's rows are in flight: one lane per channel
+    if (fused_mean) {  // last step of the mean, while the rows are in flight: one lane per channel
       if (t < D) {
         const int64_t bh = (int64_t)vb * (p.H / p.mean_group) + h / p.mean_group;
         const double* src = p.mean_partial + bh * p.mean_nsplit * D + t;
@@ -161,86 +165,95 @@ __global__ __launch_bounds__(256) void quant_per_block_kernel(QuantParams p) {
         }
         const unsigned short km = store_cvt<DT>((float)(s / (double)p.mean_S));
         smean[t] = load_cvt<DT>(km);
-        if (blk == 0 && p.mean_out != nullptr) p.mean_out[bh * D + t] = km;
+        if (blk0 == 0 && p.mean_out != nullptr) p.mean_out[bh * D + t] = km;
       }
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 8; ++i) mean[i] = smean[c * 8 + i];
     }
   }
-  float xs[NP][8];
-  float amax = 0.f;
+  float xs[NB][NP][8];
+  float amax[NB];
 #pragma unroll
-  for (int ps = 0; ps < NP; ++ps) {
-    const int row = blk * BLK + ps * RPP + rl;
-    float v[8];
-    unpack8<DT>(raw[ps], v);
-    if constexpr (HAS_DOT) {
-      float dot = 0.f;
+  for (int nb = 0; nb < NB; ++nb) {
+    amax[nb] = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) dot += v[i] * vec[i];
+    for (int ps = 0; ps < NP; ++ps) {
+      const int row = (blk0 + nb) * BLK + ps * RPP + rl;
+      float v[8];
+      unpack8<DT>(raw[nb][ps], v);
+      if constexpr (HAS_DOT) {
+        float dot = 0.f;
 #pragma unroll
-      for (int o = CPR / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
-      if (c == 0 && row < S) p.rowdot_out[((int64_t)b * p.H + h) * S + row] = load_cvt<DT>(store_cvt<DT>(dot));
+        for (int i = 0; i < 8; ++i) dot += v[i] * vec[i];
+#pragma unroll
+        for (int o = CPR / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+        if (c == 0 && row < S) p.rowdot_out[((int64_t)b * p.H + h) * S + row] = load_cvt<DT>(store_cvt<DT>(dot));
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float x = v[i];
+        // `k - km` is an elementwise op in the storage dtype (quant_per_block.py:186-187): the fp32 difference
+        // is rounded to that dtype, as the CPU oracle (and torch/paddle CPU) does.  Rows past the end stay 0:
+        // the reference subtracts on the real tensor, then loads masked rows as 0.
+        if constexpr (HAS_MEAN) x = (row < S) ? load_cvt<DT>(store_cvt<DT>(x - mean[i])) : 0.f;
+        x *= p.sm_scale;
+        xs[nb][ps][i] = x;
+        amax[nb] = fmaxf(amax[nb], fabsf(x));
+      }
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float x = v[i];
-      // `k - km` is an elementwise op in the storage dtype (quant_per_block.py:186-187): the fp32 difference
-      // is rounded to that dtype, as the CPU oracle (and torch/paddle CPU) does.  Rows past the end stay 0:
-      // the reference subtracts on the real tensor, then loads masked rows as 0.
-      if constexpr (HAS_MEAN) x = (row < S) ? load_cvt<DT>(store_cvt<DT>(x - mean[i])) : 0.f;
-      x *= p.sm_scale;
-      xs[ps][i] = x;
-      amax = fmaxf(amax, fabsf(x));
-    }
+    amax[nb] = wave_max_nonneg(amax[nb]);
+    if ((t & 63) == 0) wmax[nb][t >> 6] = amax[nb];
   }
-  amax = wave_max(amax);
-  if ((t & 63) == 0) wmax[t >> 6] = amax;
   __syncthreads();
-  amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-  const float scale = fmaxf(amax, 1e-7f) / p.qmax;
-  if (t == 0) p.scale[sbase + (int64_t)h * p.scale_h + (int64_t)blk * p.scale_blk] = scale;
 
   // y = xs / scale must be the correctly rounded fp32 quotient (the codes are bit-exact against the oracle).
   // A full IEEE division per element costs ~12 VALU ops; the divisor is the same for the whole block, so use
   // Markstein's sequence with the correctly rounded reciprocal: q0 = x*r, e = fma(-q0, s, x) (exact),
   // q1 = fma(e, r, q0) == RN(x/s) for every x unless the significand of s is all ones (checked on 1.2e8
   // adversarial samples; theorem: Markstein 1990), in which case the plain division is used.
-  const float rcp = 1.0f / scale;
-  const bool exact_rcp_ok =
-      (__builtin_amdgcn_readfirstlane(__float_as_uint(scale)) & 0x7fffffu) != 0x7fffffu;  // block-uniform
-  auto encode = [&](auto fast_tag) {
-    constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
-    for (int ps = 0; ps < NP; ++ps) {
-      const int row = blk * BLK + ps * RPP + rl;
-      int q[8];
+  for (int nb = 0; nb < NB; ++nb) {
+    const int blk = blk0 + nb;
+    if (blk * BLK >= S) break;  // workgroup-uniform: a block past the end of the sequence owns no scale slot
+    const float am = fmaxf(fmaxf(wmax[nb][0], wmax[nb][1]), fmaxf(wmax[nb][2], wmax[nb][3]));
+    const float scale = fmaxf(am, 1e-7f) / p.qmax;
+    if (t == 0) p.scale[sbase + (int64_t)h * p.scale_h + (int64_t)blk * p.scale_blk] = scale;
+    const float rcp = 1.0f / scale;
+    const bool exact_rcp_ok =
+        (__builtin_amdgcn_readfirstlane(__float_as_uint(scale)) & 0x7fffffu) != 0x7fffffu;  // block-uniform
+    auto encode = [&](auto fast_tag) {
+      constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float xv = xs[ps][i];
-        float y;
-        if constexpr (FAST) {
-          const float q0 = xv * rcp;
-          y = __builtin_fmaf(__builtin_fmaf(-q0, scale, xv), rcp, q0);
-        } else {
-          y = xv / scale;
+      for (int ps = 0; ps < NP; ++ps) {
+        const int row = blk * BLK + ps * RPP + rl;
+        int q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float xv = xs[nb][ps][i];
+          float y;
+          if constexpr (FAST) {
+            const float q0 = xv * rcp;
+            y = __builtin_fmaf(__builtin_fmaf(-q0, scale, xv), rcp, q0);
+          } else {
+            y = xv / scale;
+          }
+          // round half away from zero (:174-176): y + 0.5*sign(y), then truncate (v_cvt_i32_f32 truncates)
+          q[i] = (int)(y + __builtin_copysignf(0.5f, y));
         }
-        // round half away from zero (:174-176): y + 0.5*sign(y), then truncate (v_cvt_i32_f32 truncates)
-        q[i] = (int)(y + __builtin_copysignf(0.5f, y));
+        // |q| <= 127: v_cvt_pk_i16_i32 keeps the low bytes, v_perm_b32 gathers bytes 0 and 2 of each pair
+        const unsigned p01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(q[0], q[1]));
+        const unsigned p23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(q[2], q[3]));
+        const unsigned p45 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(q[4], q[5]));
+        const unsigned p67 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(q[6], q[7]));
+        const unsigned w0 = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
+        const unsigned w1 = __builtin_amdgcn_perm(p67, p45, 0x06040200u);
+        if (row < S) *reinterpret_cast<uint2*>(obase + (int64_t)row * p.os) = make_uint2(w0, w1);
       }
-      // |q| <= 127: v_cvt_pk_i16_i32 keeps the low bytes, v_perm_b32 gathers bytes 0 and 2 of each pair
-      const unsigned p01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(q[0], q[1]));
-      const unsigned p23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(q[2], q[3]));
-      const unsigned p45 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(q[4], q[5]));
-      const unsigned p67 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(q[6], q[7]));
-      const unsigned w0 = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
-      const unsigned w1 = __builtin_amdgcn_perm(p67, p45, 0x06040200u);
-      if (row < S) *reinterpret_cast<uint2*>(obase + (int64_t)row * p.os) = make_uint2(w0, w1);
-    }
-  };
-  if (exact_rcp_ok) encode(std::true_type{});
-  else encode(std::false_type{});
+    };
+    if (exact_rcp_ok) encode(std::true_type{});
+    else encode(std::false_type{});
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -387,10 +400,14 @@ hipError_t launch_mean_seq(const void* x, int dtype, void* out, void* ws, int B,
   return hipGetLastError();
 }
 
+#ifndef LBFA_QNB
+#define LBFA_QNB 2  // 64-row blocks per workgroup of the K quantiser
+#endif
 hipError_t launch_quant_per_block(const QuantParams& p, int dtype, int D, int blk, hipStream_t stream) {
-  dim3 grid(p.nblk, p.H, p.B);
+  const int nb = blk == 64 ? LBFA_QNB : 1;
+  dim3 grid((p.nblk + nb - 1) / nb, p.H, p.B);
   const bool hm = p.mean != nullptr, hd = p.rowdot_vec != nullptr;
-#define LBFA_Q(DT, DD, BB, HM, HD) hipLaunchKernelGGL((quant_per_block_kernel<DT, DD, BB, HM, HD>), grid, dim3(256), 0, stream, p)
+#define LBFA_Q(DT, DD, BB, HM, HD) hipLaunchKernelGGL((quant_per_block_kernel<DT, DD, BB, HM, HD, (BB == 64 ? LBFA_QNB : 1)>), grid, dim3(256), 0, stream, p)
 #define LBFA_Q1(DT, DD, BB)                          \
   do {                                               \
     if (hm && hd) LBFA_Q(DT, DD, BB, true, true);    \

@@ -46,12 +46,13 @@ namespace lbfa {
 #endif
 // Interleave inside the tile (sched_group_barrier): 0 = one long VALU phase, then the PV MFMAs under s_setprio; 1 = the PV
 // MFMAs of the first 32-key block pinned between the exponentials of the second; 2 = per 16-key k-step (PV of step r - 1
-// between the exponentials of step r).  Measured against 0 / 1: D = 64 +4 % / +1 % for 2; D = 128 -1..-3 % for 1 and 2.
+// between the exponentials of step r).  Measured against 0 / 1: D = 64 +4 % / +1 % for 2; D = 128: -1..-3 % without, 0..+2 %
+// with the raised priority over the interleaved region (LBFA_ILV_PRIO).
 #ifndef LBFA_ILV64
 #define LBFA_ILV64 2
 #endif
 #ifndef LBFA_ILV128
-#define LBFA_ILV128 0
+#define LBFA_ILV128 2
 #endif
 #define LBFA_ILV(D) ((D) == 64 ? LBFA_ILV64 : LBFA_ILV128)
 // Non-causal: every other ROUND of Q blocks of a head (a round = the workgroups one XCD runs at a time) walks the key tiles

@@ -40,10 +40,12 @@ namespace lbfa {
 // fp16 P row sums: 0 = fp32 v_add on the VALU, 2 = on the matrix pipe (v_mfma_f32_4x4x4_16b_f16 with an all-ones A operand, each lane
 // sums its own values).  Measured (C2 / S=16K / D=128 / C3, TFLOP/s, same box): VALU 980 / 1120 / 1214 / 1289, MFMA 990 / 1137 /
 // 1190 / 1286, all-ones 32x32x16 MFMA (16 accumulator registers, two waves per SIMD at D = 64) 853 / 996: MFMA sums at D = 64
-// where the VALU is the busier pipe, VALU sums at D = 128 where the matrix pipe is.
-#ifndef LBFA_LSUM
-#define LBFA_LSUM(D) ((D) == 64 ? 2 : 0)
+// where the VALU is the busier pipe, VALU sums at D = 128 where the matrix pipe is (re-measured on the interleaved D = 128
+// path: +1 % at S = 4K, 0 at C3 - left on the VALU).
+#ifndef LBFA_LSUM128
+#define LBFA_LSUM128 0
 #endif
+#define LBFA_LSUM(D) ((D) == 64 ? 2 : LBFA_LSUM128)
 // Interleave inside the tile (sched_group_barrier): 0 = one long VALU phase, then the PV MFMAs under s_setprio; 1 = the PV
 // MFMAs of the first 32-key block pinned between the exponentials of the second; 2 = per 16-key k-step (PV of step r - 1
 // between the exponentials of step r).  Measured against 0 / 1: D = 64 +4 % / +1 % for 2; D = 128: -1..-3 % without, 0..+2 %

@@ -21,6 +21,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 //  4 as 3 with 4x4x4 MFMA row sums
 //  5 as 3, no row sums at all (lower bound of the pipelined stream)
 //  6 MFMAs only (12 per tile)       7 VALU only (32 fma + 32 exp + 16 cvt)
+//  8 as 0 and 9 as 3 with the 16x16 MFMA shapes (8 x i32_16x16x64_i8 + 16 x f32_16x16x32_f16 per tile: same FLOPs, same
+//    accumulator registers) - does the chip hold a higher clock on them (MI355X_MICROARCH.md, DVFS give-back item 7)?
 template <int V>
 __global__ __launch_bounds__(256, 2) void tile_loop(float* out, long long* cyc, int iters, float sc, float c1) {
   const int lane = threadIdx.x & 63;
@@ -45,7 +47,23 @@ __global__ __launch_bounds__(256, 2) void tile_loop(float* out, long long* cyc, 
   for (int k = 0; k < 4; ++k)
     for (int e = 0; e < 8; ++e) pf[k][e] = pfn[k][e] = (_Float16)0.5f;
 
+  constexpr bool S16 = (V == 8 || V == 9);
+  i32x4 cmagic4 = {0x4B400000, 0x4B400000, 0x4B400000, 0x4B400000};
+  asm volatile("" : "+v"(cmagic4));
+  f32x4 acc16[8];
+  for (int i = 0; i < 8; ++i) acc16[i] = f32x4{0, 0, 0, 0};
   auto qk = [&](float (&dst)[2][16]) __attribute__((always_inline)) {
+    if constexpr (S16) {  // 4 key blocks x 2 row blocks of 16x16, K = 64 in one MFMA
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int rbk = 0; rbk < 2; ++rbk) {
+          const i32x4 sacc = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf[kb], qf[rbk], cmagic4, 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dst[kb >> 1][8 * (kb & 1) + 4 * rbk + i] = __int_as_float(sacc[i]);
+        }
+      return;
+    }
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2) {
       i32x16 s = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[2 * kb2], qf[0], cmagic, 0, 0, 0);
@@ -68,6 +86,14 @@ __global__ __launch_bounds__(256, 2) void tile_loop(float* out, long long* cyc, 
   };
   auto pv = [&](f16x8 (&p)[4], auto kb2_tag, bool msum) __attribute__((always_inline)) {
     constexpr int kb2 = decltype(kb2_tag)::value;
+    if constexpr (S16) {  // per 32-key half: 4 channel blocks x 2 row blocks of 16x16x32
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int rbk = 0; rbk < 2; ++rbk)
+          acc16[2 * cb + rbk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[cb], p[2 * kb2 + rbk], acc16[2 * cb + rbk], 0, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const int ks = 2 * kb2 + g;
@@ -85,12 +111,13 @@ __global__ __launch_bounds__(256, 2) void tile_loop(float* out, long long* cyc, 
   __syncthreads();
   const long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it) {
-    kf[0][0] += 1;  // the score product is not loop-invariant
-    if constexpr (V == 0 || V == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kf[i][0] += 1;  // no score MFMA is loop-invariant
+    if constexpr (V == 0 || V == 1 || V == 8) {
       qk(x);
-      sm(x, pf, K0{}, V == 0);
+      sm(x, pf, K0{}, V != 1);
       pv(pf, K0{}, V == 1);
-      sm(x, pf, K1{}, V == 0);
+      sm(x, pf, K1{}, V != 1);
       pv(pf, K1{}, V == 1);
     } else if constexpr (V == 2) {
       qk(x);
@@ -105,15 +132,15 @@ __global__ __launch_bounds__(256, 2) void tile_loop(float* out, long long* cyc, 
       }
       __builtin_amdgcn_sched_barrier(0);
       pv(pf, K1{}, true);
-    } else if constexpr (V == 3 || V == 4 || V == 5) {
+    } else if constexpr (V == 3 || V == 4 || V == 5 || V == 9) {
       // tile t: exponentiate x -> pfn ; meanwhile QK of tile t+1 -> xn and PV of tile t-1 from pf
       qk(xn);
       pv(pf, K0{}, V == 4);
       pv(pf, K1{}, V == 4);
-      sm(x, pfn, K0{}, V == 3);
-      sm(x, pfn, K1{}, V == 3);
-      constexpr int NM = (V == 4) ? 20 : 12;
-      constexpr int NV = (V == 3) ? 112 / NM : 80 / NM;
+      sm(x, pfn, K0{}, V == 3 || V == 9);
+      sm(x, pfn, K1{}, V == 3 || V == 9);
+      constexpr int NM = (V == 4) ? 20 : (V == 9) ? 24 : 12;
+      constexpr int NV = (V == 3 || V == 9) ? 112 / NM : 80 / NM;
 #pragma unroll
       for (int i = 0; i < NM; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -145,6 +172,7 @@ __global__ __launch_bounds__(256, 2) void tile_loop(float* out, long long* cyc, 
   const long long t1 = __builtin_amdgcn_s_memtime();
   float s = l + l4[0];
   for (int i = 0; i < 16; ++i) s += acc_o[0][i] + acc_o[1][i] + x[0][i] + x[1][i];
+  for (int i = 0; i < 8; ++i) s += acc16[i][0] + acc16[i][3];
   for (int k = 0; k < 4; ++k) s += (float)pf[k][0];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
   if (lane == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
@@ -173,7 +201,8 @@ void run(const char* name) {
     hipMemcpy(h.data(), cyc, grid * 4 * 8, hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
     const double wave_cyc = (double)h[h.size() / 2] / iters;  // cycles one wave needs per tile
-    printf("%-46s waves/SIMD=%d  wave: %7.1f cyc/tile   SIMD: %7.1f cyc/wave-tile   wall %.3f ms\n", name, occ, wave_cyc, wave_cyc / occ, ms);
+    printf("%-46s waves/SIMD=%d  wave: %7.1f cyc/tile   wall %.3f ms = %6.1f ns per wave-tile and SIMD   clock %.2f GHz\n", name, occ, wave_cyc,
+           ms, ms * 1e6 / (iters * occ), wave_cyc * iters / (ms * 1e6));
     hipFree(out);
     hipFree(cyc);
   }
@@ -186,6 +215,8 @@ int main() {
   run<3>("3 pipelined across tiles, VALU sums");
   run<4>("4 pipelined across tiles, 4x4x4 sums");
   run<5>("5 pipelined across tiles, no sums");
+  run<8>("8 serial, VALU sums, 16x16 MFMA shapes");
+  run<9>("9 pipelined, VALU sums, 16x16 MFMA shapes");
   run<6>("6 MFMA only (4 i8 + 8 f16)");
   run<7>("7 VALU only (32 fma+exp, 16 cvt)");
   return 0;

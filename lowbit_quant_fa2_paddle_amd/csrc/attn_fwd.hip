@@ -817,7 +817,16 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
   LBFA_STAMP(5);
 }
 
+// fp16-P variants run on the 16x16 MFMA shapes (attn_fwd16.hip); fp8 PV stays here
+#ifndef LBFA_SH16
+#define LBFA_SH16 1
+#endif
+hipError_t launch16_attn_fwd(const AttnParams& p, int D, int v_dtype, int o_dtype, int causal, hipStream_t stream);
+hipError_t launch16_attn_fwd_qq(const AttnParams& p, int D, int dtype, int causal, hipStream_t stream);
+hipError_t launch16_attn_fwd_f16(const AttnParams& p, int D, int dtype, int causal, hipStream_t stream);
+
 hipError_t launch_attn_fwd(const AttnParams& p, int D, int v_dtype, int o_dtype, int causal, hipStream_t stream) {
+  if (LBFA_SH16 && v_dtype != LBFA_E4M3) return launch16_attn_fwd(p, D, v_dtype, o_dtype, causal, stream);
   const unsigned n = (unsigned)p.B * p.Hq * p.nQ;
   dim3 grid(n), block(256);
 #define LBFA_A(DD, VT, OT)                                                                                 \
@@ -846,6 +855,7 @@ hipError_t launch_attn_fwd(const AttnParams& p, int D, int v_dtype, int o_dtype,
 
 // int8 K codes, Q quantised inside the kernel from its fp16 / bf16 source (dtype = Q's = O's); V of the same dtype or e4m3
 hipError_t launch_attn_fwd_qq(const AttnParams& p, int D, int dtype, int v_fp8, int causal, hipStream_t stream) {
+  if (LBFA_SH16 && !v_fp8) return launch16_attn_fwd_qq(p, D, dtype, causal, stream);
   const unsigned n = (unsigned)p.B * p.Hq * p.nQ;
   dim3 grid(n), block(256);
 #define LBFA_QQ(DD, VT, DT)                                                                                       \
@@ -872,6 +882,7 @@ hipError_t launch_attn_fwd_qq(const AttnParams& p, int D, int dtype, int v_fp8, 
 
 // un-quantised Q / K / V of one dtype (fp16, or bf16 converted to fp16 on the way into LDS / registers)
 hipError_t launch_attn_fwd_f16(const AttnParams& p, int D, int dtype, int causal, hipStream_t stream) {
+  if (LBFA_SH16) return launch16_attn_fwd_f16(p, D, dtype, causal, stream);
   const unsigned n = (unsigned)p.B * p.Hq * p.nQ;
   dim3 grid(n), block(256);
 #define LBFA_F(DD, DT)                                                                                \

@@ -1,0 +1,696 @@
+// Fused low-bit FlashAttention-2 forward for gfx950, fp16-P variants, on the 16x16 MFMA shapes
+// (v_mfma_i32_16x16x64_i8 for QK^T, v_mfma_f32_16x16x32_f16 for PV).
+//
+// Same operator, same tiling in the large (one workgroup = 4 waves = one 128-row Q block, 32 query rows per wave, 64-key K / V
+// tiles by LDS-DMA, double-buffered, lazy softmax reference with a deferred overflow vote, see attn_fwd.hip) - but every matrix
+// product is cut into 16x16 output blocks.  Why: on this part the same FLOPs cost fewer cycles AND hold a higher clock on the
+// 16x16 shapes (tools/ubench_tile.hip: the MFMA + softmax stream of one tile without memory traffic takes 290 ns per wave
+// and SIMD on them against 400 ns on the 32x32 shapes: -14 % cycles, +19 % clock; MI355X_MICROARCH.md "DVFS give-back" item 7).
+// At D = 64 one i8 MFMA spans the whole head dim (K = 64): the eight score MFMAs of a tile are independent - no accumulate
+// chains in front of the softmax - and the first blocks are ready while the later ones still run.
+//
+// Lane roles (i = lane & 15, g = lane >> 4):
+//   S^T = K Q^T   A = K fragment: key 16 kb + i, row bytes [64 s + 16 g, +16)      (ds_read_b128, one per (kb, s), both row blocks)
+//                 B = Q fragment: query 16 rb + i of the wave, same bytes            (registers, whole kernel)
+//                 C: lane holds, for ITS query 16 rb + i, the keys 16 kb + 4 g + {0..3}: 2 x 4 x 4 = 32 scores per tile
+//   O^T += V^T P^T  B = P^T fragment of k-step s (32 keys): element j = score of key 32 s + 16 (j >> 2) + 4 g + (j & 3) - the
+//                 lane's own registers of key blocks 2 s and 2 s + 1, converted pairwise: P never touches LDS
+//                 A = V^T fragment with the SAME key order: two ds_read_b64_tr_b16 (rows 32 s + 4 g + {0..3} and + 16) of the
+//                 row-major V tile; one fragment serves both row blocks
+//                 C: lane holds, for its query, channels 16 cb + 4 g + {0..3}
+//   A query row's scores live in four lanes (g = 0..3): row max / row sum need two cross-group steps, which only the exact
+//   path (masked tiles, re-run) and the epilogue take.
+// LDS images (checked conflict-free by enumeration of the hardware's lane groups):
+//   K tile [64][RB bytes]: 16-byte chunk c of row r at c ^ kx16(r), kx16 = (r >> 1) & 3 | r & 7 | r & 15 for RB = 64 | 128 | 256
+//   V tile [64][2 D bytes]: 32-byte block c of row r at c ^ vx16(r), vx16 = (r >> 1) & 3 (D = 64) | r & 7 (D = 128)
+// fp8 PV (one operand = all 64 keys of a tile) stays on the 32x32x64 block-scaled MFMA in attn_fwd.hip.
+#include "attn_common.h"
+
+namespace lbfa {
+
+#ifndef LBFA_THR
+#define LBFA_THR 8.0f
+#endif
+#ifndef LBFA_PINGPONG
+#define LBFA_PINGPONG 1
+#endif
+#ifndef LBFA_VRAW
+#define LBFA_VRAW 1
+#endif
+#ifndef LBFA_LSUM16_64
+#define LBFA_LSUM16_64 2  // D = 64 row sums: 2 = v_mfma_f32_4x4x4_16b_f16 (matrix pipe), 0 = v_add_f32
+#endif
+#ifndef LBFA_LSUM16_128
+#define LBFA_LSUM16_128 0
+#endif
+
+template <int RB>
+__device__ __forceinline__ int kx16(int row) {  // K-tile 16-byte chunk swizzle, rows of RB bytes
+  if constexpr (RB == 64) return (row >> 1) & 3;
+  else if constexpr (RB == 128) return row & 7;
+  else return row & 15;
+}
+template <int D>
+__device__ __forceinline__ int vx16(int row) {  // V-tile 32-byte block swizzle
+  if constexpr (D == 64) return (row >> 1) & 3;
+  else return row & 7;
+}
+// sum / max over the four lanes l, l + 16, l + 32, l + 48 that share a query row
+__device__ __forceinline__ float group4_sum(float x) {
+  x += __shfl_xor(x, 16, 64);
+  return x + __shfl_xor(x, 32, 64);
+}
+__device__ __forceinline__ float group4_max(float x) {
+  x = fmaxf(x, __shfl_xor(x, 16, 64));
+  return fmaxf(x, __shfl_xor(x, 32, 64));
+}
+__device__ __forceinline__ void rowsum_mfma16(f32x4& l_acc, const f16x8& pfrag) {  // each lane: += sum of its own 8 values
+  const f16x4 ones4 = f16x4{(_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f};
+  l_acc = __builtin_amdgcn_mfma_f32_4x4x4f16(ones4, f16x4{pfrag[0], pfrag[1], pfrag[2], pfrag[3]}, l_acc, 0, 0, 0);
+  l_acc = __builtin_amdgcn_mfma_f32_4x4x4f16(ones4, f16x4{pfrag[4], pfrag[5], pfrag[6], pfrag[7]}, l_acc, 0, 0, 0);
+}
+
+#ifdef LBFA_STAMPS16  // diagnostic build only (tools/stamps.py): s_memtime at six points of a workgroup's life, wave 0 lane 0
+__device__ long long g_stamps16[8192 * 8];
+#define LBFA_STAMP(k)                                                                                              \
+  do {                                                                                                             \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps16[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();    \
+  } while (0)
+extern "C" int lbfa_debug_stamps(void* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps16), sizeof(g_stamps16), 0, hipMemcpyDeviceToHost);
+}
+#else
+#define LBFA_STAMP(k)
+#endif
+
+template <int D, int QT, int VT, int OT, bool CAUSAL, bool QQ = false>
+__global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnParams p) {
+  static_assert(!QQ || QT == kQInt8, "in-kernel Q quantisation belongs to the int8 path");
+  static_assert(VT != LBFA_E4M3, "fp8 PV runs in attn_fwd.hip");
+  constexpr bool QK16 = (QT != kQInt8);
+  constexpr int ESZ = QK16 ? 2 : 1;        // bytes per Q / K element
+  constexpr int RB = D * ESZ;              // bytes per K row
+  constexpr float THR = LBFA_THR;
+  constexpr int KS = RB / 64;              // k-steps of the score product: 64 row bytes per MFMA (64 int8 or 32 fp16)
+  constexpr int CB = D / 16;               // 16-channel blocks of O^T
+  constexpr int KBYTES = 64 * RB, VBYTES = 128 * D;
+  constexpr int KCH = KBYTES / 4096, VCH = VBYTES / 4096;  // 16-byte chunks per thread
+  constexpr bool DMA_V = (VT != LBFA_BF16);  // bf16 V is converted to fp16 on the way in: registers + ds_write
+  constexpr int TILES_BYTES = 2 * (KBYTES + VBYTES);
+  __shared__ __attribute__((aligned(16))) char smem[TILES_BYTES + 16];  // ONE LDS object (see attn_fwd.hip)
+
+  LBFA_STAMP(0);
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int i16 = lane & 15, g = lane >> 4;
+
+  // ---- which (batch, head, q-block) -----------------------------------------------------------------
+  const unsigned w_id = xcd_remap(blockIdx.x, gridDim.x);
+  int qt = (int)(w_id % (unsigned)p.nQ);
+  const int bh = (int)(w_id / (unsigned)p.nQ);
+  if constexpr (CAUSAL) qt = p.nQ - 1 - qt;  // heaviest q-blocks of a head first
+  const int b = bh / p.Hq, h = bh % p.Hq, hk = h / p.group;
+
+  int Sq = p.Sq, Sk = p.Sk, nK = p.nK;
+  int64_t q_off = (int64_t)b * p.qb, k_off = (int64_t)b * p.kb, v_off = (int64_t)b * p.vb, o_off = (int64_t)b * p.ob;
+  int64_t qsc_base = (int64_t)b * p.qsc_b, ksc_base = (int64_t)b * p.ksc_b;
+  if (p.cu_q != nullptr) {  // packed variable-length batch (attn_qk_int8_block_varlen.py:125-141); lengths cut at the maxima
+    const int q0 = p.cu_q[b], k0 = p.cu_k[b];
+    Sq = min(p.cu_q[b + 1] - q0, p.Sq);
+    Sk = min(p.cu_k[b + 1] - k0, p.Sk);
+    if (qt * 128 >= Sq) return;  // whole workgroup, before any barrier
+    nK = (Sk + 63) >> 6;
+    q_off = (int64_t)q0 * p.qs;
+    k_off = (int64_t)k0 * p.ks;
+    v_off = (int64_t)k0 * p.vs;
+    o_off = (int64_t)q0 * p.os;
+    if (p.cu_qscale != nullptr) {
+      qsc_base = (int64_t)p.cu_qscale[b] * p.qsc_b;
+      ksc_base = (int64_t)p.cu_kscale[b] * p.ksc_b;
+    }
+  }
+  const int row0 = qt * 128 + wave * 32;  // first query row of this wave
+  auto qrow_of = [&](int rb) __attribute__((always_inline)) { return row0 + 16 * rb + i16; };
+
+  // ---- operand windows (bytes) ------------------------------------------------------------------------
+  const int dq_valid = QK16 ? p.d_valid : D;
+  const char* kbase = (const char*)p.k + ESZ * (k_off + (int64_t)hk * p.kh);
+  const int64_t k_bytes = ESZ * ((int64_t)(Sk - 1) * p.ks + dq_valid);
+  const int64_t k_tile_stride = ESZ * 64 * p.ks;
+  const char* vbase = (const char*)p.v + 2 * (v_off + (int64_t)hk * p.vh);
+  const int64_t v_bytes = 2 * ((int64_t)(Sk - 1) * p.vs + p.d_valid);
+  const int64_t v_tile_stride = 128 * p.vs;
+
+  // ---- loop-invariant per-thread offsets of the tile fetch (one 16-byte chunk per thread and pass of 256 threads) ----
+  constexpr int KCPR = RB / 16, KROWS = 256 / KCPR;
+  constexpr int VCPR = D / 8, VROWS = 256 / VCPR;
+  unsigned k_goff, v_goff, v_loff;
+  {
+    const int row = t / KCPR, ch = t % KCPR;
+    const int gch = ch ^ kx16<RB>(row);  // LDS-DMA writes linearly: the slot (row, ch) holds global chunk ch ^ kx16(row)
+    k_goff = gch * 16 < ESZ * dq_valid ? ESZ * (unsigned)row * (unsigned)p.ks + gch * 16 : 0x80000000u;
+  }
+  {
+    const int row = t / VCPR, ch = t % VCPR;
+    const int sw = (((ch >> 1) ^ vx16<D>(row)) << 1) | (ch & 1);
+    const int gch = DMA_V ? sw : ch;
+    v_goff = gch * 8 < p.d_valid ? 2 * ((unsigned)row * (unsigned)p.vs) + gch * 16 : 0x80000000u;
+    v_loff = 2 * KBYTES + row * (2 * D) + sw * 16;
+  }
+  const unsigned k_gstep = ESZ * KROWS * (unsigned)p.ks;
+  const unsigned v_gstep = 2u * VROWS * (unsigned)p.vs;
+  static_assert(KROWS * RB == 4096 && VROWS * 2 * D == 4096, "one pass of 256 threads x 16 bytes");
+  u32x4 vreg[DMA_V ? 1 : VCH];
+  const int k_bytes32 = (int)k_bytes, v_bytes32 = (int)v_bytes, k_stride32 = (int)k_tile_stride, v_stride32 = (int)v_tile_stride;
+  typedef __attribute__((address_space(3))) void* lds_void_ptr;
+  auto load_tile = [&](int j, auto buf_tag) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    const bool in_range = (unsigned)j < (unsigned)nK;  // the look-ahead past either end gets a window of 0 bytes
+    const int ko = in_range ? j * k_stride32 : 0, vo = in_range ? j * v_stride32 : 0;
+    const int k_rem = in_range ? max(0, k_bytes32 - ko) : 0, v_rem = in_range ? max(0, v_bytes32 - vo) : 0;
+    const __amdgpu_buffer_rsrc_t k_rs = make_rsrc(kbase + ko, (unsigned)k_rem);
+    const __amdgpu_buffer_rsrc_t v_rs = make_rsrc(vbase + vo, (unsigned)v_rem);
+    char* kdst = smem + BUF * KBYTES + wave * 1024;  // DMA destination: wave-uniform base (+ 16 bytes per lane, implicit)
+#pragma unroll
+    for (int c = 0; c < KCH; ++c)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rs, (lds_void_ptr)(kdst + c * 4096), 16, (int)k_goff, (int)(c * k_gstep), 0, 0);
+    if constexpr (DMA_V) {
+      char* vdst = smem + 2 * KBYTES + BUF * VBYTES + wave * 1024;
+#pragma unroll
+      for (int c = 0; c < VCH; ++c)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rs, (lds_void_ptr)(vdst + c * 4096), 16, (int)v_goff, (int)(c * v_gstep), 0, 0);
+    } else {
+#pragma unroll
+      for (int c = 0; c < VCH; ++c) vreg[c] = buf_load16(v_rs, v_goff, c * v_gstep);
+    }
+  };
+  auto store_tile = [&](auto buf_tag) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    if constexpr (!DMA_V) {
+#pragma unroll
+      for (int c = 0; c < VCH; ++c) {
+        u32x4 val = bf16x8_to_f16x8(vreg[c]);  // bf16 -> fp16 on the way in (src/core.py:307-308 `v.to(float16)`)
+        *reinterpret_cast<u32x4*>(smem + v_loff + c * 4096 + BUF * VBYTES) = val;
+      }
+    }
+  };
+
+  // processing order of the key tiles (ping-pong per round of Q blocks, see attn_fwd.hip)
+  constexpr int kRound = (D == 64) ? 96 : 64;
+  const bool rev = !CAUSAL && (LBFA_PINGPONG != 0) && ((Sk & 63) == 0) && (((qt / kRound) & 1) != 0);
+  auto tile_of = [&](int i) __attribute__((always_inline)) { return rev ? nK - 1 - i : i; };
+  load_tile(tile_of(0), std::integral_constant<int, 0>{});
+  const float* ksc = nullptr;
+  if constexpr (!QK16) ksc = p.k_scale + ksc_base + (int64_t)hk * p.ksc_h;
+  const int ksc_blk = (int)p.ksc_blk;
+  float ks_first = 0.f;
+  if constexpr (!QK16) ks_first = lane < nK ? ksc[lane * ksc_blk] : 0.f;
+
+  // ---- Q fragments: lane (i, g) holds row bytes [64 s + 16 g, +16) of query rows 16 rb + i ------------------------
+  i32x4 qf[2][KS];
+  float qsc = 1.0f;
+  float row_corr[2] = {0.f, 0.f};
+  if constexpr (QQ) {
+    // in-kernel Q quantiser: same arithmetic as quant_per_block_kernel (src/triton/quant_per_block.py:132-178)
+    const char* qsrc = (const char*)p.q + 2 * (q_off + (int64_t)h * p.qh);
+    const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(qsrc, (unsigned)(2 * ((int64_t)(Sq - 1) * p.qs + p.d_valid)));
+    float xs[2][KS][16];
+    float amax = 0.f;
+    const unsigned short* vec = p.q_dot_vec ? p.q_dot_vec + ((int64_t)b * p.Hkv + hk) * D : nullptr;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      float dot = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int col = 64 * s + 16 * g + 8 * hf;
+          const u32x4 raw = buf_load16(q_rs, col < p.d_valid ? 2 * ((unsigned)qrow_of(rb) * (unsigned)p.qs + col) : 0x80000000u, 0);
+          float xv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            xv[e] = load_cvt<OT>((unsigned short)((e & 1) ? (raw[e >> 1] >> 16) : (raw[e >> 1] & 0xffffu)));
+            const float x = xv[e] * p.q_sm_scale;
+            xs[rb][s][8 * hf + e] = x;
+            amax = fmaxf(amax, fabsf(x));
+          }
+          if (vec != nullptr) {
+            const u32x4 vraw = *reinterpret_cast<const u32x4*>(vec + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              dot += xv[e] * load_cvt<OT>((unsigned short)((e & 1) ? (vraw[e >> 1] >> 16) : (vraw[e >> 1] & 0xffffu)));
+          }
+        }
+      row_corr[rb] = load_cvt<OT>(store_cvt<OT>(group4_sum(dot)));  // rounded to the storage dtype (src/core.py:294-304)
+    }
+    amax = wave_max_nonneg(amax);
+    LBFA_STAMP(6);
+    float* red = reinterpret_cast<float*>(smem + TILES_BYTES);
+    if (lane == 0) red[wave] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    LBFA_STAMP(7);
+    const float scale = fmaxf(amax, 1e-7f) / p.q_qmax;
+    qsc = scale;
+    const float rcp = 1.0f / scale;
+    const bool exact_rcp_ok = (__builtin_amdgcn_readfirstlane(__float_as_uint(scale)) & 0x7fffffu) != 0x7fffffu;
+    auto encode = [&](auto fast_tag) __attribute__((always_inline)) {
+      constexpr bool FAST = decltype(fast_tag)::value;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          unsigned w[4];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            int qv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float xv = xs[rb][s][4 * g4 + e];
+              float y;
+              if constexpr (FAST) {
+                const float q0 = xv * rcp;
+                y = __builtin_fmaf(__builtin_fmaf(-q0, scale, xv), rcp, q0);
+              } else {
+                y = xv / scale;
+              }
+              qv[e] = (int)(y + __builtin_copysignf(0.5f, y));
+            }
+            const unsigned p01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(qv[0], qv[1]));
+            const unsigned p23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(qv[2], qv[3]));
+            w[g4] = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
+          }
+          qf[rb][s] = i32x4{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+        }
+    };
+    if (exact_rcp_ok) encode(std::true_type{});
+    else encode(std::false_type{});
+  } else {
+    const char* qbase = (const char*)p.q + ESZ * (q_off + (int64_t)h * p.qh);
+    const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(qbase, (unsigned)(ESZ * ((int64_t)(Sq - 1) * p.qs + dq_valid)));
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const unsigned col_b = 64 * s + 16 * g;  // byte column
+        u32x4 raw = buf_load16(q_rs, col_b < (unsigned)(ESZ * dq_valid) ? ESZ * (unsigned)qrow_of(rb) * (unsigned)p.qs + col_b : 0x80000000u, 0);
+        qf[rb][s] = __builtin_bit_cast(i32x4, raw);
+      }
+    if constexpr (!QK16) qsc = p.q_scale[qsc_base + (int64_t)h * p.qsc_h + (int64_t)qt * p.qsc_blk];
+  }
+
+  LBFA_STAMP(1);
+  int n_tiles = nK;
+  if constexpr (CAUSAL) n_tiles = min(nK, 2 * (qt + 1));
+
+  // ---- fragment read addresses (lane parts; block / k-step / buffer parts are immediates) ------------------------
+  const unsigned kf_lane = i16 * RB + ((g ^ kx16<RB>(i16)) << 4);  // k-step s: ^ (s << 6)
+  unsigned vf_base[CB];
+  {
+    const int vr = 4 * g + (i16 >> 2);  // row within a 16-key group of the tile (+ 32 s + 16 half as immediates)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) vf_base[cb] = 2 * KBYTES + vr * (2 * D) + ((cb ^ vx16<D>(vr)) << 5) + (i16 & 3) * 8;
+  }
+  // V fragments of DMA-fed tiles are read by hand-issued ds_read_b64_tr_b16 (attn_common.h, lds_read_tr16_raw): the compiler then
+  // orders nothing against the prefetch in flight, so the tile loop waits for it itself - vmcnt(0) in front of each barrier
+  constexpr bool VRAW = DMA_V && (LBFA_VRAW != 0);
+  unsigned vf_addr[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) vf_addr[cb] = lds_offset_of(smem) + vf_base[cb];
+
+  // ---- running state --------------------------------------------------------------------------------
+  constexpr bool MSUM = (D == 64 ? LBFA_LSUM16_64 : LBFA_LSUM16_128) == 2;
+  f32x4 acc_o[2][CB];
+  f32x4 l_acc[2];
+  float m_run[2], l_run[2];
+  auto reset_state = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc_o[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      l_acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      m_run[rb] = -INFINITY;
+      l_run[rb] = 0.f;
+    }
+  };
+  reset_state();
+  i32x4 cmagic = i32x4{kMagicBits, kMagicBits, kMagicBits, kMagicBits};
+  asm volatile("" : "+v"(cmagic));
+
+  // ---- exact bias folding (see attn_fwd.hip): constants on a common power-of-two grid ------------------------------
+  float ks_max = 0.f;
+  if constexpr (!QK16) {
+    ks_max = ks_first;
+    for (int i = lane + 64; i < nK; i += 64) ks_max = fmaxf(ks_max, ksc[i * ksc_blk]);
+    ks_max = fmaxf(wave_max_nonneg(ks_max), 1e-30f);
+  }
+  const float sc_max = qsc * ks_max;
+  const int gexp = (int)((__float_as_uint(1.25f * kMagic * sc_max) >> 23) & 0xff) - 127 + 1 - 21;  // log2(G)
+  const float G = __builtin_ldexpf(1.0f, gexp), invG = __builtin_ldexpf(1.0f, -gexp);
+  const float gg = __builtin_ldexpf(1.0f, gexp - 22), invg = __builtin_ldexpf(1.0f, 22 - gexp);
+  auto grid_up = [&](float m) __attribute__((always_inline)) { return __builtin_ceilf(m * invG) * G; };
+  float sc_tab = 0.f, c0_tab = 0.f;
+  auto refresh_scale_table = [&](int j0) __attribute__((always_inline)) {
+    if constexpr (!QK16) {
+      const int jt = j0 + lane;
+      const float ks_l = j0 == 0 ? ks_first : (jt < nK ? ksc[jt * ksc_blk] : 0.f);
+      sc_tab = fmaxf(__builtin_rintf(qsc * ks_l * invg), 1.0f) * gg;  // >= one grid step: a masked key must not meet sc = 0
+      c0_tab = -kMagic * sc_tab;
+    }
+  };
+
+  auto compute_tile = [&](auto buf_tag, int j, auto masked_tag, auto exact_tag, auto prime_tag) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    constexpr bool EXACT = decltype(exact_tag)::value || MASKED;
+    constexpr bool PRIME = decltype(prime_tag)::value;
+    const char* kbuf = smem + BUF * KBYTES;
+    const char* vbuf = smem + BUF * VBYTES;
+    float sc, c0;
+    if constexpr (QK16) {
+      sc = p.qk_scale;
+      c0 = 0.f;
+    } else {
+      sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc_tab), j & 63));
+      c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c0_tab), j & 63));
+    }
+    float x[2][4][4];  // [row block][key block][key 4 g + e]: kMagic + s (accumulator bits), then P in place
+    auto compute_scores = [&](auto kb_tag) __attribute__((always_inline)) {
+      constexpr int kb = decltype(kb_tag)::value;
+      i32x4 sacc[2];
+      f32x4 facc[2];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const i32x4 kf = *reinterpret_cast<const i32x4*>(kbuf + (kf_lane ^ (unsigned)(s << 6)) + kb * 16 * RB);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          if constexpr (QT == LBFA_BF16) {
+            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            const bf16x8 ka = __builtin_bit_cast(bf16x8, kf), qb = __builtin_bit_cast(bf16x8, qf[rb][s]);
+            if (s == 0) facc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            else facc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qb, facc[rb], 0, 0, 0);
+          } else if constexpr (QK16) {
+            const f16x8 ka = __builtin_bit_cast(f16x8, kf), qb = __builtin_bit_cast(f16x8, qf[rb][s]);
+            if (s == 0) facc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            else facc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qb, facc[rb], 0, 0, 0);
+          } else {
+            if (s == 0) sacc[rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf, qf[rb][s], cmagic, 0, 0, 0);
+            else sacc[rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf, qf[rb][s], sacc[rb], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float tv;
+          if constexpr (QK16) tv = facc[rb][e];
+          else tv = __int_as_float(sacc[rb][e]);
+          if constexpr (MASKED) {
+            const int key = j * 64 + 16 * kb + 4 * g + e;
+            bool dead = key >= Sk;
+            if constexpr (CAUSAL) dead = dead || (key > qrow_of(rb));
+            if (dead) tv = -INFINITY;
+          }
+          x[rb][kb][e] = tv;
+        }
+    };
+    auto update_reference = [&](float thr) __attribute__((always_inline)) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tmax = fmaxf(tmax, x[rb][kb][e]);
+        tmax = group4_max(tmax);
+        const float xmax = __builtin_fmaf(tmax, sc, c0);
+        const float m_cand = fmaxf(m_run[rb], QK16 ? xmax : grid_up(xmax));
+        if (__any(m_cand > m_run[rb] + thr)) {
+          const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_cand);  // m_run = -inf -> 0
+          m_run[rb] = m_cand;
+          l_run[rb] *= alpha;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) l_acc[rb][e] *= alpha;
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc_o[rb][cb][e] *= alpha;
+        }
+      }
+    };
+    f16x8 pf[2][2];  // [row block][k-step of 32 keys]
+    float psum[2] = {0.f, 0.f};
+    float c1[2];
+    // P of one k-step (key blocks 2 s, 2 s + 1) of one row block, in place, + the packed P^T fragment
+    auto exp_s = [&](auto rb_tag, auto s_tag) __attribute__((always_inline)) {
+      constexpr int rb = decltype(rb_tag)::value, s = decltype(s_tag)::value;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          x[rb][2 * s + k2][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[rb][2 * s + k2][e], sc, c1[rb]));
+          if constexpr (!MSUM) psum[rb] += x[rb][2 * s + k2][e];
+        }
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pf[rb][s][4 * k2 + e] = (_Float16)x[rb][2 * s + k2][e];
+    };
+    // O^T += V^T P^T for one k-step: every V^T fragment is read once and serves both row blocks
+    auto pv_s = [&](auto s_tag) __attribute__((always_inline)) {
+      constexpr int s = decltype(s_tag)::value;
+      if constexpr (VRAW) {
+        static_for<0, CB / 4>([&](auto q4) {
+          constexpr int c0 = 4 * decltype(q4)::value;
+          constexpr int off = BUF * VBYTES + (32 * s) * (2 * D);
+          f16x4 vlo[4], vhi[4];
+          static_for<0, 4>([&](auto c) {
+            constexpr int ci = decltype(c)::value;
+            vlo[ci] = lds_read_tr16_raw<off>(vf_addr[c0 + ci]);
+            vhi[ci] = lds_read_tr16_raw<off + 16 * 2 * D>(vf_addr[c0 + ci]);
+          });
+          lds_wait_all(vlo[0], vhi[0], vlo[1], vhi[1], vlo[2], vhi[2], vlo[3], vhi[3]);
+          static_for<0, 4>([&](auto c) {
+            constexpr int ci = decltype(c)::value, cb = c0 + ci;
+            const f16x8 vf = f16x8{vlo[ci][0], vlo[ci][1], vlo[ci][2], vlo[ci][3], vhi[ci][0], vhi[ci][1], vhi[ci][2], vhi[ci][3]};
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) acc_o[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[rb][s], acc_o[rb][cb], 0, 0, 0);
+          });
+        });
+        if constexpr (MSUM) {
+          rowsum_mfma16(l_acc[0], pf[0][s]);
+          rowsum_mfma16(l_acc[1], pf[1][s]);
+        }
+      } else {
+        static_for<0, CB>([&](auto c) {
+          constexpr int cb = decltype(c)::value;
+          const f16x4 vlo = lds_read_tr16(vbuf + vf_base[cb] + (32 * s) * (2 * D));
+          const f16x4 vhi = lds_read_tr16(vbuf + vf_base[cb] + (32 * s + 16) * (2 * D));
+          const f16x8 vf = f16x8{vlo[0], vlo[1], vlo[2], vlo[3], vhi[0], vhi[1], vhi[2], vhi[3]};
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) acc_o[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[rb][s], acc_o[rb][cb], 0, 0, 0);
+          if constexpr (MSUM && cb == CB - 1) {
+            rowsum_mfma16(l_acc[0], pf[0][s]);
+            rowsum_mfma16(l_acc[1], pf[1][s]);
+          }
+        });
+      }
+    };
+    using R0 = std::integral_constant<int, 0>;
+    using R1 = std::integral_constant<int, 1>;
+
+    static_for<0, 4>([&](auto kb) { compute_scores(kb); });
+    if constexpr (PRIME) {
+      update_reference(0.0f);
+      return;
+    }
+    if constexpr (EXACT) update_reference(THR);
+    c1[0] = c0 - m_run[0];  // exact (grid argument); +inf while m_run = -inf
+    c1[1] = c0 - m_run[1];
+    exp_s(R0{}, R0{});
+    exp_s(R1{}, R0{});
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    pv_s(R0{});
+    exp_s(R0{}, R1{});
+    exp_s(R1{}, R1{});
+    {
+      constexpr int NM = 2 * CB + (MSUM ? 4 : 0);
+      constexpr int NV = (MSUM ? 40 : 56) / NM > 0 ? (MSUM ? 40 : 56) / NM : 1;
+      static_for<0, NM>([&](auto) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+      });
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    pv_s(R1{});
+    if constexpr (!MSUM) {
+      l_run[0] += psum[0];
+      l_run[1] += psum[1];
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- tile loop (structure of attn_fwd.hip) ---------------------------------------------------------------------
+  int n_main = n_tiles;
+  if constexpr (CAUSAL) n_main = min(n_tiles, 2 * qt);
+  else if ((Sk & 63) != 0) n_main = n_tiles - 1;
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  using No = std::false_type;
+  using Yes = std::true_type;
+  auto step = [&](auto buf_tag, auto nbuf_tag, int i, auto masked_tag, auto exact_tag) __attribute__((always_inline)) {
+    const int j = tile_of(i);
+    if (i != 0 && (j & 63) == (rev ? 63 : 0)) refresh_scale_table(j & ~63);
+    load_tile(tile_of(i + 1), nbuf_tag);
+    bool skip = false;
+    if constexpr (decltype(masked_tag)::value && CAUSAL) skip = j * 64 > row0 + 31;  // all keys above all rows of this wave
+    if (!skip) compute_tile(buf_tag, j, masked_tag, exact_tag, No{});
+    store_tile(nbuf_tag);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile has landed (this wave's share) when the barrier opens
+    __syncthreads();
+  };
+  auto run_tiles = [&](auto exact_tag) __attribute__((always_inline)) {
+    constexpr bool EX = decltype(exact_tag)::value;
+    refresh_scale_table(tile_of(0) & ~63);
+    store_tile(B0{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (!EX) {
+      if (n_main > 0) compute_tile(B0{}, tile_of(0), No{}, No{}, Yes{});  // reference <- exact row max of the first tile
+    }
+    int i = 0;
+    for (; i + 1 < n_main; i += 2) {
+      step(B0{}, B1{}, i, No{}, exact_tag);
+      step(B1{}, B0{}, i + 1, No{}, exact_tag);
+    }
+    for (; i < n_tiles; i += 2) {
+      if (i < n_main) step(B0{}, B1{}, i, No{}, exact_tag);
+      else step(B0{}, B1{}, i, Yes{}, exact_tag);
+      if (i + 1 < n_tiles) {
+        if (i + 1 < n_main) step(B1{}, B0{}, i + 1, No{}, exact_tag);
+        else step(B1{}, B0{}, i + 1, Yes{}, exact_tag);
+      }
+    }
+  };
+
+  LBFA_STAMP(2);
+  run_tiles(No{});
+  LBFA_STAMP(3);
+  float l_tot[2];
+  auto row_sum = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) l_tot[rb] = group4_sum(MSUM ? l_acc[rb][0] : l_run[rb]);
+  };
+  row_sum();
+  {
+    // deferred fp16-overflow vote (see attn_fwd.hip): one decision per workgroup
+    int* flag = reinterpret_cast<int*>(smem + TILES_BYTES);
+    float chk = l_tot[0] + l_tot[1];
+    if constexpr (!MSUM) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) chk += fabsf(acc_o[rb][cb][e]);
+    }
+    const int bad = __any(!(chk < INFINITY)) ? 1 : 0;
+    if (lane == 0) flag[wave] = bad;
+    __syncthreads();
+    const int any_bad = flag[0] | flag[1] | flag[2] | flag[3];
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(any_bad)) {
+      reset_state();
+      load_tile(tile_of(0), B0{});
+      run_tiles(Yes{});
+      row_sum();
+    }
+  }
+
+  LBFA_STAMP(4);
+  // ---- epilogue: O = O^T / l, LSE ------------------------------------------------------------------------------
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const int qrow = qrow_of(rb);
+    const float inv_l = l_tot[rb] > 0.f ? 1.0f / l_tot[rb] : 0.f;
+    if (qrow < Sq) {
+      unsigned short* op = reinterpret_cast<unsigned short*>(p.o) + o_off + (int64_t)h * p.oh + (int64_t)qrow * p.os;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const int d0 = 16 * cb + 4 * g;
+        if (d0 >= p.d_valid) continue;  // d_valid is a multiple of 8
+        uint2 pk;
+        pk.x = (unsigned)store_cvt<OT>(acc_o[rb][cb][0] * inv_l) | ((unsigned)store_cvt<OT>(acc_o[rb][cb][1] * inv_l) << 16);
+        pk.y = (unsigned)store_cvt<OT>(acc_o[rb][cb][2] * inv_l) | ((unsigned)store_cvt<OT>(acc_o[rb][cb][3] * inv_l) << 16);
+        *reinterpret_cast<uint2*>(op + d0) = pk;
+      }
+      if (p.lse != nullptr && g == 0) {
+        float ls = log2f(l_tot[rb]) + m_run[rb];  // base-2 domain (attn_qk_int8_per_block.py:164-167)
+        const int64_t li = ((int64_t)b * p.Hq + h) * p.Sq + qrow;
+        ls *= p.lse_scale;
+        if constexpr (QQ) ls += row_corr[rb] * p.lse_corr_scale;
+        else if (p.lse_corr != nullptr) ls += p.lse_corr[li] * p.lse_corr_scale;
+        p.lse[li] = ls;
+      }
+    }
+  }
+  LBFA_STAMP(5);
+}
+
+// ---- launchers (called from attn_fwd.hip's launch_* for every fp16-P variant) ----------------------------------------
+hipError_t launch16_attn_fwd(const AttnParams& p, int D, int v_dtype, int o_dtype, int causal, hipStream_t stream) {
+  dim3 grid((unsigned)p.B * p.Hq * p.nQ), block(256);
+#define LBFA_A(DD, VT, OT)                                                                                   \
+  do {                                                                                                       \
+    if (causal) hipLaunchKernelGGL((attn_fwd16_kernel<DD, kQInt8, VT, OT, true>), grid, block, 0, stream, p);  \
+    else hipLaunchKernelGGL((attn_fwd16_kernel<DD, kQInt8, VT, OT, false>), grid, block, 0, stream, p);        \
+  } while (0)
+#define LBFA_A2(DD, VT)                                   \
+  do {                                                    \
+    if (o_dtype == LBFA_F16) LBFA_A(DD, VT, LBFA_F16);    \
+    else LBFA_A(DD, VT, LBFA_BF16);                       \
+  } while (0)
+#define LBFA_A3(DD)                                       \
+  do {                                                    \
+    if (v_dtype == LBFA_F16) LBFA_A2(DD, LBFA_F16);       \
+    else LBFA_A2(DD, LBFA_BF16);                          \
+  } while (0)
+  if (D == 64) LBFA_A3(64);
+  else LBFA_A3(128);
+#undef LBFA_A3
+#undef LBFA_A2
+#undef LBFA_A
+  return hipGetLastError();
+}
+
+hipError_t launch16_attn_fwd_qq(const AttnParams& p, int D, int dtype, int causal, hipStream_t stream) {
+  dim3 grid((unsigned)p.B * p.Hq * p.nQ), block(256);
+#define LBFA_QQ(DD, DT)                                                                                         \
+  do {                                                                                                          \
+    if (causal) hipLaunchKernelGGL((attn_fwd16_kernel<DD, kQInt8, DT, DT, true, true>), grid, block, 0, stream, p); \
+    else hipLaunchKernelGGL((attn_fwd16_kernel<DD, kQInt8, DT, DT, false, true>), grid, block, 0, stream, p);       \
+  } while (0)
+  if (D == 64) { if (dtype == LBFA_F16) LBFA_QQ(64, LBFA_F16); else LBFA_QQ(64, LBFA_BF16); }
+  else { if (dtype == LBFA_F16) LBFA_QQ(128, LBFA_F16); else LBFA_QQ(128, LBFA_BF16); }
+#undef LBFA_QQ
+  return hipGetLastError();
+}
+
+hipError_t launch16_attn_fwd_f16(const AttnParams& p, int D, int dtype, int causal, hipStream_t stream) {
+  dim3 grid((unsigned)p.B * p.Hq * p.nQ), block(256);
+#define LBFA_F(DD, DT)                                                                                  \
+  do {                                                                                                  \
+    if (causal) hipLaunchKernelGGL((attn_fwd16_kernel<DD, DT, DT, DT, true>), grid, block, 0, stream, p);  \
+    else hipLaunchKernelGGL((attn_fwd16_kernel<DD, DT, DT, DT, false>), grid, block, 0, stream, p);        \
+  } while (0)
+  if (D == 64) { if (dtype == LBFA_F16) LBFA_F(64, LBFA_F16); else LBFA_F(64, LBFA_BF16); }
+  else { if (dtype == LBFA_F16) LBFA_F(128, LBFA_F16); else LBFA_F(128, LBFA_BF16); }
+#undef LBFA_F
+  return hipGetLastError();
+}
+
+}  // namespace lbfa

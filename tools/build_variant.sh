@@ -9,7 +9,7 @@ C=lowbit_quant_fa2_paddle_amd/csrc
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize $extra"
 rm -f /tmp/lbfa_var_$name/*.o $out
 pids=""
-for f in lbfa_api quant_kernels attn_fwd; do
+for f in lbfa_api quant_kernels attn_fwd attn_fwd16; do
   /opt/rocm/bin/hipcc $FLAGS -c $C/$f.hip -o /tmp/lbfa_var_$name/$f.o &
   pids="$pids $!"
 done

@@ -32,6 +32,9 @@ print(f"workgroups {len(st)}  kernel span {(st[:,5].max()-t0):.0f} cycles")
 for i, nm in enumerate(names):
     print(f"{nm:26s} median {np.median(d[:, i]):9.0f}  mean {d[:, i].mean():9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}  share {d[:, i].sum() / tot.sum():6.3f}")
 print(f"{'total per WG':26s} median {np.median(tot):9.0f}")
+if st[:, 6].any():  # in-kernel Q quantiser: 0 -> 6 loads + amax, 6 -> 7 workgroup reduction, 7 -> 1 encode
+    for nm, a, b in (("  Q loads + amax", 0, 6), ("  block amax (2 barriers)", 6, 7), ("  encode", 7, 1)):
+        print(f"{nm:26s} median {np.median(st[:, b] - st[:, a]):9.0f}")
 # start-time histogram: how staggered are the workgroups
 start = np.sort(st[:, 0] - t0)
 print("start times (cycles) percentiles 10/50/90:", np.percentile(start, [10, 50, 90]).round())

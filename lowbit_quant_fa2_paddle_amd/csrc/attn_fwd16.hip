@@ -34,14 +34,20 @@ namespace lbfa {
 #ifndef LBFA_PINGPONG
 #define LBFA_PINGPONG 1
 #endif
+#ifndef LBFA_VGRP64
+#define LBFA_VGRP64 2  // channel blocks per batch of V^T reads: 4 costs the D = 64 loop a scratch reload per tile (168 registers)
+#endif
+#ifndef LBFA_VGRP128
+#define LBFA_VGRP128 4
+#endif
 #ifndef LBFA_VRAW
 #define LBFA_VRAW 1
 #endif
 #ifndef LBFA_LSUM16_64
-#define LBFA_LSUM16_64 2  // D = 64 row sums: 2 = v_mfma_f32_4x4x4_16b_f16 (matrix pipe), 0 = v_add_f32
+#define LBFA_LSUM16_64 3  // row sums: 3 = one more 16x16x32 PV MFMA against an all-ones V^T block, 2 = v_mfma_f32_4x4x4_16b_f16, 0 = v_add_f32
 #endif
 #ifndef LBFA_LSUM16_128
-#define LBFA_LSUM16_128 0
+#define LBFA_LSUM16_128 3
 #endif
 
 template <int RB>
@@ -321,7 +327,18 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   for (int cb = 0; cb < CB; ++cb) vf_addr[cb] = lds_offset_of(smem) + vf_base[cb];
 
   // ---- running state --------------------------------------------------------------------------------
-  constexpr bool MSUM = (D == 64 ? LBFA_LSUM16_64 : LBFA_LSUM16_128) == 2;
+  // Row sums.  The SIMD's vector issue port is the scarce resource of the tile loop (MI355X_MICROARCH.md, per-instruction issue
+  // costs: plain VALU 4 cycles, v_exp_f32 8, an MFMA 8), so the sums ride on the matrix pipe: O^T gets a (D/16 + 1)-th
+  // channel block whose V^T rows are all ones - one more 16x16x32 MFMA per row block and k-step (8 issue cycles for 128
+  // additions; 32 v_add_f32 would take 128) - and every accumulator element of that block IS the complete row sum of the lane's
+  // query: no cross-lane step at the end either.
+  constexpr int LSUM = (D == 64 ? LBFA_LSUM16_64 : LBFA_LSUM16_128);
+  constexpr bool OSUM = LSUM == 3;
+  constexpr bool MSUM = LSUM == 2 || OSUM;  // sums on the matrix pipe (nothing to add on the VALU)
+  f16x8 ones8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones8[e] = (_Float16)1.0f;
+  asm volatile("" : "+v"(ones8));  // opaque: otherwise re-materialised in every tile
   f32x4 acc_o[2][CB];
   f32x4 l_acc[2];
   float m_run[2], l_run[2];
@@ -463,24 +480,29 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
     auto pv_s = [&](auto s_tag) __attribute__((always_inline)) {
       constexpr int s = decltype(s_tag)::value;
       if constexpr (VRAW) {
-        static_for<0, CB / 4>([&](auto q4) {
-          constexpr int c0 = 4 * decltype(q4)::value;
+        constexpr int VG = (D == 64) ? LBFA_VGRP64 : LBFA_VGRP128;  // channel blocks per batch of V^T reads (registers: 4 VG)
+        static_for<0, CB / VG>([&](auto q4) {
+          constexpr int c0 = VG * decltype(q4)::value;
           constexpr int off = BUF * VBYTES + (32 * s) * (2 * D);
-          f16x4 vlo[4], vhi[4];
-          static_for<0, 4>([&](auto c) {
+          f16x4 vlo[VG], vhi[VG];
+          static_for<0, VG>([&](auto c) {
             constexpr int ci = decltype(c)::value;
             vlo[ci] = lds_read_tr16_raw<off>(vf_addr[c0 + ci]);
             vhi[ci] = lds_read_tr16_raw<off + 16 * 2 * D>(vf_addr[c0 + ci]);
           });
-          lds_wait_all(vlo[0], vhi[0], vlo[1], vhi[1], vlo[2], vhi[2], vlo[3], vhi[3]);
-          static_for<0, 4>([&](auto c) {
+          if constexpr (VG == 4) lds_wait_all(vlo[0], vhi[0], vlo[1], vhi[1], vlo[2], vhi[2], vlo[3], vhi[3]);
+          else lds_wait_all(vlo[0], vhi[0], vlo[1], vhi[1]);
+          static_for<0, VG>([&](auto c) {
             constexpr int ci = decltype(c)::value, cb = c0 + ci;
             const f16x8 vf = f16x8{vlo[ci][0], vlo[ci][1], vlo[ci][2], vlo[ci][3], vhi[ci][0], vhi[ci][1], vhi[ci][2], vhi[ci][3]};
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) acc_o[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[rb][s], acc_o[rb][cb], 0, 0, 0);
           });
         });
-        if constexpr (MSUM) {
+        if constexpr (OSUM) {
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) l_acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[rb][s], l_acc[rb], 0, 0, 0);
+        } else if constexpr (MSUM) {
           rowsum_mfma16(l_acc[0], pf[0][s]);
           rowsum_mfma16(l_acc[1], pf[1][s]);
         }
@@ -492,7 +514,10 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
           const f16x8 vf = f16x8{vlo[0], vlo[1], vlo[2], vlo[3], vhi[0], vhi[1], vhi[2], vhi[3]};
 #pragma unroll
           for (int rb = 0; rb < 2; ++rb) acc_o[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[rb][s], acc_o[rb][cb], 0, 0, 0);
-          if constexpr (MSUM && cb == CB - 1) {
+          if constexpr (OSUM && cb == CB - 1) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) l_acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[rb][s], l_acc[rb], 0, 0, 0);
+          } else if constexpr (MSUM && cb == CB - 1) {
             rowsum_mfma16(l_acc[0], pf[0][s]);
             rowsum_mfma16(l_acc[1], pf[1][s]);
           }
@@ -518,7 +543,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
     exp_s(R0{}, R1{});
     exp_s(R1{}, R1{});
     {
-      constexpr int NM = 2 * CB + (MSUM ? 4 : 0);
+      constexpr int NM = 2 * CB + (OSUM ? 2 : MSUM ? 4 : 0);
       constexpr int NV = (MSUM ? 40 : 56) / NM > 0 ? (MSUM ? 40 : 56) / NM : 1;
       static_for<0, NM>([&](auto) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -583,7 +608,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   float l_tot[2];
   auto row_sum = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) l_tot[rb] = group4_sum(MSUM ? l_acc[rb][0] : l_run[rb]);
+    for (int rb = 0; rb < 2; ++rb) l_tot[rb] = OSUM ? l_acc[rb][0] : group4_sum(MSUM ? l_acc[rb][0] : l_run[rb]);
   };
   row_sum();
   {

@@ -35,6 +35,24 @@ print(f"{'total per WG':26s} median {np.median(tot):9.0f}")
 if st[:, 6].any():  # in-kernel Q quantiser: 0 -> 6 loads + amax, 6 -> 7 workgroup reduction, 7 -> 1 encode
     for nm, a, b in (("  Q loads + amax", 0, 6), ("  block amax (2 barriers)", 6, 7), ("  encode", 7, 1)):
         print(f"{nm:26s} median {np.median(st[:, b] - st[:, a]):9.0f}")
+# The counter is per XCD (blockIdx % 8, unsynchronised): slot utilisation and the idle time between a workgroup's end and its
+# successor's start are computed within each XCD.
+slots = 32 * (3 if D == 64 else 2)
+for x in range(8):
+    idx = np.arange(x, len(st), 8)
+    s0, s5 = st[idx, 0], st[idx, 5]
+    span = s5.max() - s0.min()
+    busy = (s5 - s0).sum() / slots
+    # greedy slot reconstruction: each start takes over the slot that ended last before it
+    ends = np.sort(s5)
+    gaps = []
+    for t_start in np.sort(s0)[slots:]:
+        k = np.searchsorted(ends, t_start) - 1
+        if k >= 0:
+            gaps.append(t_start - ends[k])
+    if x < 2 or x == 7:
+        print(f"XCD {x}: span {span:9.0f} cycles, slots busy {busy / span:6.3f}, start-after-end gap median {np.median(gaps) if gaps else 0:7.0f} "
+              f"(min over predecessors), first-round start spread {np.sort(s0)[:slots].max() - s0.min():7.0f}")
 # start-time histogram: how staggered are the workgroups
 start = np.sort(st[:, 0] - t0)
 print("start times (cycles) percentiles 10/50/90:", np.percentile(start, [10, 50, 90]).round())

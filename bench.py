@@ -415,7 +415,7 @@ def main():
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "frac_of_fp16_roof": round(achieved / PEAK_F16_TF, 4),
                          "hbm_GBps": (round(traffic / (kern_ms * 1e-3) / 1e9, 1) if (traffic and kern_ms > 0) else None),
-                         "kernel": "attn_fwd_kernel", "kernel_ms": round(kern_ms, 4), "kernel_ms_median": round(kern_med, 4),
+                         "kernel": ("attn_fwd_kernel" if api == "int8_fp8" else "attn_fwd16_kernel"), "kernel_ms": round(kern_ms, 4), "kernel_ms_median": round(kern_med, 4),
                          "peak_note": ("int8 MFMA for QK^T and block-scaled e4m3 MFMA for PV: 5000 both" if api == "int8_fp8" else
                                        "mixed roof 1/(0.5/5000 + 0.5/2500): half the FLOPs int8 MFMA, half fp16 MFMA")},
             "cpu_baseline": cpu,

@@ -1,0 +1,77 @@
+"""The LDS images of attn_fwd16.hip are bank-conflict-free for the kernel's fragment reads: enumeration of every lane group.
+
+Model (MI355X_MICROARCH.md, LDS): 64 banks x 4 bytes, bank = (address / 4) mod 64.  A ds_read_b128 is served in four fixed,
+NON-contiguous groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32; 16 lanes x 16 bytes = all 64 banks
+once): conflict-free iff the 16 lanes of a group touch 16 different bank quads, i.e. (address / 16) mod 16 are all different.
+A ds_read_b64(_tr_b16) is served 32 lanes at a time ({0-31}, {32-63}): (address / 8) mod 32 all different.
+The address formulas below restate the kernel's (kx16 / vx16, kf_lane, vf_base in attn_fwd16.hip) - if the kernel changes its
+swizzle, this test has to change with it; it documents WHY the swizzles are what they are."""
+import pytest
+
+
+def kx16(rb, row):
+    return {64: (row >> 1) & 3, 128: row & 7, 256: row & 15}[rb]
+
+
+B128_GROUPS = [
+    [0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+    [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31],
+]
+B128_GROUPS += [[lane + 32 for lane in grp] for grp in B128_GROUPS]
+
+
+def vx16(d, row):
+    return (row >> 1) & 3 if d == 64 else row & 7
+
+
+@pytest.mark.parametrize("rb", [64, 128, 256])
+def test_k_fragment_reads_conflict_free(rb):
+    ks = rb // 64
+    for kb in range(4):
+        for s in range(ks):
+            for grp in B128_GROUPS:
+                quads = set()
+                for lane in grp:
+                    i16, g = lane & 15, lane >> 4
+                    addr = (kb * 16 + i16) * rb + (((4 * s + g) ^ kx16(rb, i16)) << 4)
+                    assert addr % 16 == 0 and addr < 64 * rb
+                    quads.add((addr // 16) % 16)
+                assert len(quads) == 16, (rb, kb, s, grp)
+
+
+@pytest.mark.parametrize("rb", [64, 128, 256])
+def test_k_image_is_a_permutation_of_the_tile(rb):
+    # the DMA writes slot (row, ch) linearly and fetches global chunk ch ^ kx16(row): every chunk of a row lands exactly once,
+    # and the fragment read of chunk c finds it at slot c ^ kx16(row)
+    cpr = rb // 16
+    for row in range(64):
+        src = [ch ^ kx16(rb, row) for ch in range(cpr)]
+        assert sorted(src) == list(range(cpr))
+        for c in range(cpr):
+            assert src[c ^ kx16(rb, row)] == c
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_v_transposed_reads_conflict_free(d):
+    cb_n = d // 16
+    for s in range(2):
+        for half in range(2):
+            for cb in range(cb_n):
+                for grp in range(2):  # 32 lanes served together
+                    slots = set()
+                    for lane in range(32 * grp, 32 * grp + 32):
+                        i16, g = lane & 15, lane >> 4
+                        vr = 4 * g + (i16 >> 2)
+                        row = 32 * s + 16 * half + vr
+                        addr = row * 2 * d + ((cb ^ vx16(d, vr)) << 5) + (i16 & 3) * 8
+                        assert vx16(d, row) == vx16(d, vr)  # the swizzle only sees row bits the immediates leave alone
+                        slots.add((addr // 8) % 32)
+                    assert len(slots) == 32, (d, s, half, cb, grp)
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_v_image_is_a_permutation_of_the_tile(d):
+    cpr = d // 8  # 16-byte chunks per row; the swizzle permutes 32-byte blocks
+    for row in range(64):
+        src = [(((ch >> 1) ^ vx16(d, row)) << 1) | (ch & 1) for ch in range(cpr)]
+        assert sorted(src) == list(range(cpr))

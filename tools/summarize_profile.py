@@ -9,6 +9,16 @@ os.makedirs("profiles", exist_ok=True)
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)  # gpurun merges runs: older files of the same tag may linger
 ks = newest(f"{src}/kt/*/*_kernel_stats.csv")
 shutil.copy(ks, f"profiles/{tag}_{wl}_kernel_stats.csv")
+
+
+def is_lowbit_attention(k):
+    """The low-bit attention kernel of a workload: attn_fwd16_kernel<D, QT = 3 (int8 codes), ...> or the fp8-PV attn_fwd_kernel<...>
+    (QT = 0 / 1 instances of attn_fwd16_kernel are the un-quantised fp16 / bf16 kernel bench.py times as a comparison point)."""
+    if "attn_fwd16_kernel<" in k:
+        return k.split("<", 1)[1].split(",")[1].strip() == "3"
+    return "attn_fwd_kernel<" in k
+
+
 out = {}
 for d in ("pmc1", "pmc2", "pmc3", "pmc4"):
     fs = glob.glob(f"{src}/{d}/*/*_counter_collection.csv")
@@ -25,7 +35,7 @@ for d in ("pmc1", "pmc2", "pmc3", "pmc4"):
     for k, v in acc.items():
         out.setdefault(k, {}).update({c: sum(x) / len(x) for c, x in v.items()})
 for k, v in out.items():
-    if "attn_fwd" in k and ", 3, " in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:  # QT = 3: the low-bit kernel
+    if is_lowbit_attention(k) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         v["hbm_bytes_per_launch"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
         if "GRBM_GUI_ACTIVE" in v and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
             cyc = v["GRBM_GUI_ACTIVE"] / 8
@@ -37,6 +47,6 @@ for k, v in out.items():
         json.dump(t, open(tj, "w"), indent=1)
 json.dump(out, open(f"profiles/{tag}_{wl}_pmc_summary.json", "w"), indent=1)
 for k, v in out.items():
-    if "attn_fwd" in k and ", 3, " in k:
+    if is_lowbit_attention(k):
         print(k, json.dumps(v, indent=1))
 print(open(f"profiles/{tag}_{wl}_kernel_stats.csv").read()[:900])

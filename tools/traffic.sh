@@ -13,7 +13,8 @@ acc = collections.defaultdict(list)
 for d in ("pmc2", "pmc3"):
     for f in glob.glob("$out/" + d + "/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if "attn_fwd_kernel" in r["Kernel_Name"] and ", 3, " in r["Kernel_Name"]:
+            k = r["Kernel_Name"]
+            if ("attn_fwd16_kernel<" in k and k.split("<", 1)[1].split(",")[1].strip() == "3") or "attn_fwd_kernel<" in k:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 f = sum(acc["FETCH_SIZE"]) / max(len(acc["FETCH_SIZE"]), 1)
 w = sum(acc["WRITE_SIZE"]) / max(len(acc["WRITE_SIZE"]), 1)

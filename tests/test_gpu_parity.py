@@ -284,7 +284,7 @@ def test_varlen_and_dispatchers(oracle, dev):
 @pytest.mark.parametrize("causal", [False, True])
 def test_lazy_reference_rescale_branches(oracle, dev, D, causal):
     """The fp16-PV kernel exponentiates against a stale softmax reference and only moves it when a row sum
-    blows up (attn_fwd.hip, LAZY path).  That branch is rare on random data, so force it: single keys aligned
+    blows up (attn_fwd16.hip, lazy softmax reference).  That branch is rare on random data, so force it: single keys aligned
     with single queries make one row's score jump by ~60 (finite overflow of the fp16 range) and by > 127
     (fp32 exp2 overflows to +inf) in LATER tiles, plus one spike in the very first tile.  Checked against the
     oracle on the FULL tensor."""

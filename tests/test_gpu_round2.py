@@ -1,8 +1,7 @@
 """GPU parity tests added in round 2 (run with `-m gpu`): the data-dependent paths of the reworked attention kernel.
 
   * the deferred fp16-overflow check: EVERY q-block of the tensor overflows fp16 P in its first (lazy) pass and is redone
-    with the exact row max per tile (attn_fwd.hip `run_tiles(Yes)`), both row-sum schemes (D = 64: MFMA sums, D = 128:
-    VALU sums), dense + ragged + causal, against the oracle on the FULL tensor;
+    with the exact row max per tile (attn_fwd16.hip `run_tiles(Yes)`), both head dims, dense + ragged + causal, against the oracle on the FULL tensor;
   * an all-zero K block inside a MASKED tile (ragged last tile / causal diagonal): its dequantisation scale sits on the
     1e-7 floor, far below the scale grid of the head - the exponent argument of a masked key must stay -inf, not NaN;
   * a packed batch whose caller understates max_seqlen_k: sequences are cut at the stated maximum, nothing is read
@@ -164,7 +163,7 @@ def test_p_to_e4m3_conversion_bit_exact(oracle, dev):
 @pytest.mark.parametrize("variant", ["fp16", "fp8"])
 def test_reversed_rounds_of_q_blocks_vs_oracle(oracle, dev, D, S, first_rev_row, variant):
     """Non-causal kernels walk the key tiles backwards for every other ROUND of Q blocks of a head (ping-pong order for L2
-    reuse, attn_fwd.hip `tile_of`): Q blocks >= 96 (D = 64) / >= 64 (D = 128).  The rows of the first reversed round - with
+    reuse, `tile_of` in attn_fwd16.hip / attn_fwd.hip): Q blocks >= 96 (D = 64) / >= 64 (D = 128).  The rows of the first reversed round - with
     more than 64 key tiles, so the per-64-tile scale table is refreshed downwards too - against the oracle, and a forward
     block next to them for contrast.  (fp8 at D = 64 keeps 64-block rounds.)"""
     import lowbit_quant_fa2_paddle_amd as lb

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-workgroup phase times of the attention kernel from a -DLBFA_STAMPS build (variants/lib_stamps.so).
+"""Diagnostic: per-workgroup phase times of the attention kernel from a -DLBFA_STAMPS16 build of attn_fwd16.hip (tools/build_exp.sh stamps16 "-DLBFA_STAMPS16").
    LBFA_LIB_PATH=variants/lib_stamps.so python tools/stamps.py [S] [D]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -76,7 +76,7 @@ __device__ __forceinline__ void rowsum_mfma16(f32x4& l_acc, const f16x8& pfrag) 
   l_acc = __builtin_amdgcn_mfma_f32_4x4x4f16(ones4, f16x4{pfrag[4], pfrag[5], pfrag[6], pfrag[7]}, l_acc, 0, 0, 0);
 }
 
-#ifdef LBFA_STAMPS16  // diagnostic build only (tools/stamps.py): s_memtime at six points of a workgroup's life, wave 0 lane 0
+#if defined(LBFA_STAMPS16) && LBFA_D16 == 64  // diagnostic build only, D = 64 unit (tools/stamps.py): s_memtime at six points of a workgroup's life, wave 0 lane 0
 __device__ long long g_stamps16[8192 * 8];
 #define LBFA_STAMP(k)                                                                                              \
   do {                                                                                                             \
@@ -667,53 +667,56 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
 }
 
 // ---- launchers (called from attn_fwd.hip's launch_* for every fp16-P variant) ----------------------------------------
-hipError_t launch16_attn_fwd(const AttnParams& p, int D, int v_dtype, int o_dtype, int causal, hipStream_t stream) {
+// This file is compiled TWICE (Makefile: -DLBFA_D16=64 -> attn_fwd16_d64.o, -DLBFA_D16=128 -> attn_fwd16_d128.o): each
+// translation unit instantiates the kernels of one head dim and exports launch16_*_d64 / _d128 - the two halves build in parallel.
+#ifndef LBFA_D16
+#error "compile with -DLBFA_D16=64 or -DLBFA_D16=128"
+#endif
+#define LBFA_CAT2(a, b) a##b
+#define LBFA_CAT(a, b) LBFA_CAT2(a, b)
+#define LBFA_DNAME(fn) LBFA_CAT(fn, LBFA_D16)
+
+hipError_t LBFA_DNAME(launch16_attn_fwd_d)(const AttnParams& p, int v_dtype, int o_dtype, int causal, hipStream_t stream) {
   dim3 grid((unsigned)p.B * p.Hq * p.nQ), block(256);
-#define LBFA_A(DD, VT, OT)                                                                                   \
-  do {                                                                                                       \
-    if (causal) hipLaunchKernelGGL((attn_fwd16_kernel<DD, kQInt8, VT, OT, true>), grid, block, 0, stream, p);  \
-    else hipLaunchKernelGGL((attn_fwd16_kernel<DD, kQInt8, VT, OT, false>), grid, block, 0, stream, p);        \
+#define LBFA_A(VT, OT)                                                                                            \
+  do {                                                                                                            \
+    if (causal) hipLaunchKernelGGL((attn_fwd16_kernel<LBFA_D16, kQInt8, VT, OT, true>), grid, block, 0, stream, p);  \
+    else hipLaunchKernelGGL((attn_fwd16_kernel<LBFA_D16, kQInt8, VT, OT, false>), grid, block, 0, stream, p);        \
   } while (0)
-#define LBFA_A2(DD, VT)                                   \
-  do {                                                    \
-    if (o_dtype == LBFA_F16) LBFA_A(DD, VT, LBFA_F16);    \
-    else LBFA_A(DD, VT, LBFA_BF16);                       \
+#define LBFA_A2(VT)                                   \
+  do {                                                \
+    if (o_dtype == LBFA_F16) LBFA_A(VT, LBFA_F16);    \
+    else LBFA_A(VT, LBFA_BF16);                       \
   } while (0)
-#define LBFA_A3(DD)                                       \
-  do {                                                    \
-    if (v_dtype == LBFA_F16) LBFA_A2(DD, LBFA_F16);       \
-    else LBFA_A2(DD, LBFA_BF16);                          \
-  } while (0)
-  if (D == 64) LBFA_A3(64);
-  else LBFA_A3(128);
-#undef LBFA_A3
+  if (v_dtype == LBFA_F16) LBFA_A2(LBFA_F16);
+  else LBFA_A2(LBFA_BF16);
 #undef LBFA_A2
 #undef LBFA_A
   return hipGetLastError();
 }
 
-hipError_t launch16_attn_fwd_qq(const AttnParams& p, int D, int dtype, int causal, hipStream_t stream) {
+hipError_t LBFA_DNAME(launch16_attn_fwd_qq_d)(const AttnParams& p, int dtype, int causal, hipStream_t stream) {
   dim3 grid((unsigned)p.B * p.Hq * p.nQ), block(256);
-#define LBFA_QQ(DD, DT)                                                                                         \
-  do {                                                                                                          \
-    if (causal) hipLaunchKernelGGL((attn_fwd16_kernel<DD, kQInt8, DT, DT, true, true>), grid, block, 0, stream, p); \
-    else hipLaunchKernelGGL((attn_fwd16_kernel<DD, kQInt8, DT, DT, false, true>), grid, block, 0, stream, p);       \
+#define LBFA_QQ(DT)                                                                                                    \
+  do {                                                                                                                 \
+    if (causal) hipLaunchKernelGGL((attn_fwd16_kernel<LBFA_D16, kQInt8, DT, DT, true, true>), grid, block, 0, stream, p); \
+    else hipLaunchKernelGGL((attn_fwd16_kernel<LBFA_D16, kQInt8, DT, DT, false, true>), grid, block, 0, stream, p);       \
   } while (0)
-  if (D == 64) { if (dtype == LBFA_F16) LBFA_QQ(64, LBFA_F16); else LBFA_QQ(64, LBFA_BF16); }
-  else { if (dtype == LBFA_F16) LBFA_QQ(128, LBFA_F16); else LBFA_QQ(128, LBFA_BF16); }
+  if (dtype == LBFA_F16) LBFA_QQ(LBFA_F16);
+  else LBFA_QQ(LBFA_BF16);
 #undef LBFA_QQ
   return hipGetLastError();
 }
 
-hipError_t launch16_attn_fwd_f16(const AttnParams& p, int D, int dtype, int causal, hipStream_t stream) {
+hipError_t LBFA_DNAME(launch16_attn_fwd_f16_d)(const AttnParams& p, int dtype, int causal, hipStream_t stream) {
   dim3 grid((unsigned)p.B * p.Hq * p.nQ), block(256);
-#define LBFA_F(DD, DT)                                                                                  \
-  do {                                                                                                  \
-    if (causal) hipLaunchKernelGGL((attn_fwd16_kernel<DD, DT, DT, DT, true>), grid, block, 0, stream, p);  \
-    else hipLaunchKernelGGL((attn_fwd16_kernel<DD, DT, DT, DT, false>), grid, block, 0, stream, p);        \
+#define LBFA_F(DT)                                                                                             \
+  do {                                                                                                         \
+    if (causal) hipLaunchKernelGGL((attn_fwd16_kernel<LBFA_D16, DT, DT, DT, true>), grid, block, 0, stream, p);   \
+    else hipLaunchKernelGGL((attn_fwd16_kernel<LBFA_D16, DT, DT, DT, false>), grid, block, 0, stream, p);         \
   } while (0)
-  if (D == 64) { if (dtype == LBFA_F16) LBFA_F(64, LBFA_F16); else LBFA_F(64, LBFA_BF16); }
-  else { if (dtype == LBFA_F16) LBFA_F(128, LBFA_F16); else LBFA_F(128, LBFA_BF16); }
+  if (dtype == LBFA_F16) LBFA_F(LBFA_F16);
+  else LBFA_F(LBFA_BF16);
 #undef LBFA_F
   return hipGetLastError();
 }

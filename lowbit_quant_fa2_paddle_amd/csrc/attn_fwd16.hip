@@ -139,6 +139,27 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   const int row0 = qt * 128 + wave * 32;  // first query row of this wave
   auto qrow_of = [&](int rb) __attribute__((always_inline)) { return row0 + 16 * rb + i16; };
 
+  // ---- Q rows of this wave: requested FIRST, in flight while the K / V fetch is set up and issued ----------------------
+  // lane (i, g) takes row bytes [64 s + 16 g, +16) of the int8 codes / 16-bit elements (QQ: the 16 fp16 source elements
+  // [64 s + 16 g, +16) as two 16-byte pieces) of query rows 16 rb + i; rows >= Sq are out of the descriptor's range: zeros
+  constexpr int QPC = QQ ? 2 : 1;
+  u32x4 qraw[2][KS][QPC];
+  {
+    constexpr int QESZ = QQ ? 2 : ESZ;  // bytes per element of the Q operand as stored
+    const int q_valid = (QQ || QK16) ? p.d_valid : D;
+    const char* qbase = (const char*)p.q + QESZ * (q_off + (int64_t)h * p.qh);
+    const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(qbase, (unsigned)(QESZ * ((int64_t)(Sq - 1) * p.qs + q_valid)));
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int hf = 0; hf < QPC; ++hf) {
+          const unsigned col_b = QQ ? 2 * (64 * s + 16 * g + 8 * hf) : 64 * s + 16 * g;  // byte column
+          qraw[rb][s][hf] = buf_load16(q_rs, col_b < (unsigned)(QESZ * q_valid) ? QESZ * (unsigned)qrow_of(rb) * (unsigned)p.qs + col_b : 0x80000000u, 0);
+        }
+  }
+
   // ---- operand windows (bytes) ------------------------------------------------------------------------
   const int dq_valid = QK16 ? p.d_valid : D;
   const char* kbase = (const char*)p.k + ESZ * (k_off + (int64_t)hk * p.kh);
@@ -213,14 +234,12 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   float ks_first = 0.f;
   if constexpr (!QK16) ks_first = lane < nK ? ksc[lane * ksc_blk] : 0.f;
 
-  // ---- Q fragments: lane (i, g) holds row bytes [64 s + 16 g, +16) of query rows 16 rb + i ------------------------
+  // ---- Q fragments (B operand of the score MFMAs) from the rows requested above --------------------------------------
   i32x4 qf[2][KS];
   float qsc = 1.0f;
   float row_corr[2] = {0.f, 0.f};
   if constexpr (QQ) {
     // in-kernel Q quantiser: same arithmetic as quant_per_block_kernel (src/triton/quant_per_block.py:132-178)
-    const char* qsrc = (const char*)p.q + 2 * (q_off + (int64_t)h * p.qh);
-    const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(qsrc, (unsigned)(2 * ((int64_t)(Sq - 1) * p.qs + p.d_valid)));
     float xs[2][KS][16];
     float amax = 0.f;
     const unsigned short* vec = p.q_dot_vec ? p.q_dot_vec + ((int64_t)b * p.Hkv + hk) * D : nullptr;
@@ -232,7 +251,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const int col = 64 * s + 16 * g + 8 * hf;
-          const u32x4 raw = buf_load16(q_rs, col < p.d_valid ? 2 * ((unsigned)qrow_of(rb) * (unsigned)p.qs + col) : 0x80000000u, 0);
+          const u32x4 raw = qraw[rb][s][hf];
           float xv[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -294,16 +313,10 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
     if (exact_rcp_ok) encode(std::true_type{});
     else encode(std::false_type{});
   } else {
-    const char* qbase = (const char*)p.q + ESZ * (q_off + (int64_t)h * p.qh);
-    const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(qbase, (unsigned)(ESZ * ((int64_t)(Sq - 1) * p.qs + dq_valid)));
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const unsigned col_b = 64 * s + 16 * g;  // byte column
-        u32x4 raw = buf_load16(q_rs, col_b < (unsigned)(ESZ * dq_valid) ? ESZ * (unsigned)qrow_of(rb) * (unsigned)p.qs + col_b : 0x80000000u, 0);
-        qf[rb][s] = __builtin_bit_cast(i32x4, raw);
-      }
+      for (int s = 0; s < KS; ++s) qf[rb][s] = __builtin_bit_cast(i32x4, qraw[rb][s][0]);
     if constexpr (!QK16) qsc = p.q_scale[qsc_base + (int64_t)h * p.qsc_h + (int64_t)qt * p.qsc_blk];
   }
 

@@ -28,27 +28,11 @@
 
 namespace lbfa {
 
-#ifndef LBFA_THR
-#define LBFA_THR 8.0f
-#endif
-#ifndef LBFA_PINGPONG
-#define LBFA_PINGPONG 1
-#endif
-#ifndef LBFA_VGRP64
-#define LBFA_VGRP64 2  // channel blocks per batch of V^T reads: 4 costs the D = 64 loop a scratch reload per tile (168 registers)
-#endif
-#ifndef LBFA_VGRP128
-#define LBFA_VGRP128 4
-#endif
-#ifndef LBFA_VRAW
-#define LBFA_VRAW 1
-#endif
-#ifndef LBFA_LSUM16_64
-#define LBFA_LSUM16_64 3  // row sums: 3 = one more 16x16x32 PV MFMA against an all-ones V^T block, 2 = v_mfma_f32_4x4x4_16b_f16, 0 = v_add_f32
-#endif
-#ifndef LBFA_LSUM16_128
-#define LBFA_LSUM16_128 3
-#endif
+constexpr float kLazyThr = 8.0f;  // exact paths move the softmax reference only when a row max outgrows it by more than 2^8
+constexpr bool kPingPong = true;  // every other round of Q blocks walks the key tiles backwards (L2 reuse, see attn_fwd.hip)
+// channel blocks per batch of V^T reads (4 registers each): 4 costs the D = 64 loop a scratch reload per tile (168 registers),
+// 2 costs D = 128 1.5 % (one more LDS round trip per k-step)
+template <int D> constexpr int kVBatch = (D == 64) ? 2 : 4;
 
 template <int RB>
 __device__ __forceinline__ int kx16(int row) {  // K-tile 16-byte chunk swizzle, rows of RB bytes
@@ -70,12 +54,6 @@ __device__ __forceinline__ float group4_max(float x) {
   x = fmaxf(x, __shfl_xor(x, 16, 64));
   return fmaxf(x, __shfl_xor(x, 32, 64));
 }
-__device__ __forceinline__ void rowsum_mfma16(f32x4& l_acc, const f16x8& pfrag) {  // each lane: += sum of its own 8 values
-  const f16x4 ones4 = f16x4{(_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f};
-  l_acc = __builtin_amdgcn_mfma_f32_4x4x4f16(ones4, f16x4{pfrag[0], pfrag[1], pfrag[2], pfrag[3]}, l_acc, 0, 0, 0);
-  l_acc = __builtin_amdgcn_mfma_f32_4x4x4f16(ones4, f16x4{pfrag[4], pfrag[5], pfrag[6], pfrag[7]}, l_acc, 0, 0, 0);
-}
-
 #if defined(LBFA_STAMPS16) && LBFA_D16 == 64  // diagnostic build only, D = 64 unit (tools/stamps.py): s_memtime at six points of a workgroup's life, wave 0 lane 0
 __device__ long long g_stamps16[8192 * 8];
 #define LBFA_STAMP(k)                                                                                              \
@@ -96,7 +74,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   constexpr bool QK16 = (QT != kQInt8);
   constexpr int ESZ = QK16 ? 2 : 1;        // bytes per Q / K element
   constexpr int RB = D * ESZ;              // bytes per K row
-  constexpr float THR = LBFA_THR;
+  constexpr float THR = kLazyThr;
   constexpr int KS = RB / 64;              // k-steps of the score product: 64 row bytes per MFMA (64 int8 or 32 fp16)
   constexpr int CB = D / 16;               // 16-channel blocks of O^T
   constexpr int KBYTES = 64 * RB, VBYTES = 128 * D;
@@ -225,7 +203,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
 
   // processing order of the key tiles (ping-pong per round of Q blocks, see attn_fwd.hip)
   constexpr int kRound = (D == 64) ? 96 : 64;
-  const bool rev = !CAUSAL && (LBFA_PINGPONG != 0) && ((Sk & 63) == 0) && (((qt / kRound) & 1) != 0);
+  const bool rev = !CAUSAL && kPingPong && ((Sk & 63) == 0) && (((qt / kRound) & 1) != 0);
   auto tile_of = [&](int i) __attribute__((always_inline)) { return rev ? nK - 1 - i : i; };
   load_tile(tile_of(0), std::integral_constant<int, 0>{});
   const float* ksc = nullptr;
@@ -334,7 +312,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   }
   // V fragments of DMA-fed tiles are read by hand-issued ds_read_b64_tr_b16 (attn_common.h, lds_read_tr16_raw): the compiler then
   // orders nothing against the prefetch in flight, so the tile loop waits for it itself - vmcnt(0) in front of each barrier
-  constexpr bool VRAW = DMA_V && (LBFA_VRAW != 0);
+  constexpr bool VRAW = DMA_V;
   unsigned vf_addr[CB];
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) vf_addr[cb] = lds_offset_of(smem) + vf_base[cb];
@@ -345,16 +323,13 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   // channel block whose V^T rows are all ones - one more 16x16x32 MFMA per row block and k-step (8 issue cycles for 128
   // additions; 32 v_add_f32 would take 128) - and every accumulator element of that block IS the complete row sum of the lane's
   // query: no cross-lane step at the end either.
-  constexpr int LSUM = (D == 64 ? LBFA_LSUM16_64 : LBFA_LSUM16_128);
-  constexpr bool OSUM = LSUM == 3;
-  constexpr bool MSUM = LSUM == 2 || OSUM;  // sums on the matrix pipe (nothing to add on the VALU)
   f16x8 ones8;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones8[e] = (_Float16)1.0f;
   asm volatile("" : "+v"(ones8));  // opaque: otherwise re-materialised in every tile
   f32x4 acc_o[2][CB];
   f32x4 l_acc[2];
-  float m_run[2], l_run[2];
+  float m_run[2];
   auto reset_state = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
@@ -362,7 +337,6 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
       for (int cb = 0; cb < CB; ++cb) acc_o[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
       l_acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
       m_run[rb] = -INFINITY;
-      l_run[rb] = 0.f;
     }
   };
   reset_state();
@@ -461,7 +435,6 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
         if (__any(m_cand > m_run[rb] + thr)) {
           const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_cand);  // m_run = -inf -> 0
           m_run[rb] = m_cand;
-          l_run[rb] *= alpha;
 #pragma unroll
           for (int e = 0; e < 4; ++e) l_acc[rb][e] *= alpha;
 #pragma unroll
@@ -472,7 +445,6 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
       }
     };
     f16x8 pf[2][2];  // [row block][k-step of 32 keys]
-    float psum[2] = {0.f, 0.f};
     float c1[2];
     // P of one k-step (key blocks 2 s, 2 s + 1) of one row block, in place, + the packed P^T fragment
     auto exp_s = [&](auto rb_tag, auto s_tag) __attribute__((always_inline)) {
@@ -482,7 +454,6 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           x[rb][2 * s + k2][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[rb][2 * s + k2][e], sc, c1[rb]));
-          if constexpr (!MSUM) psum[rb] += x[rb][2 * s + k2][e];
         }
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2)
@@ -493,7 +464,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
     auto pv_s = [&](auto s_tag) __attribute__((always_inline)) {
       constexpr int s = decltype(s_tag)::value;
       if constexpr (VRAW) {
-        constexpr int VG = (D == 64) ? LBFA_VGRP64 : LBFA_VGRP128;  // channel blocks per batch of V^T reads (registers: 4 VG)
+        constexpr int VG = kVBatch<D>;
         static_for<0, CB / VG>([&](auto q4) {
           constexpr int c0 = VG * decltype(q4)::value;
           constexpr int off = BUF * VBYTES + (32 * s) * (2 * D);
@@ -512,13 +483,8 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
             for (int rb = 0; rb < 2; ++rb) acc_o[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[rb][s], acc_o[rb][cb], 0, 0, 0);
           });
         });
-        if constexpr (OSUM) {
 #pragma unroll
-          for (int rb = 0; rb < 2; ++rb) l_acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[rb][s], l_acc[rb], 0, 0, 0);
-        } else if constexpr (MSUM) {
-          rowsum_mfma16(l_acc[0], pf[0][s]);
-          rowsum_mfma16(l_acc[1], pf[1][s]);
-        }
+        for (int rb = 0; rb < 2; ++rb) l_acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[rb][s], l_acc[rb], 0, 0, 0);
       } else {
         static_for<0, CB>([&](auto c) {
           constexpr int cb = decltype(c)::value;
@@ -527,12 +493,9 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
           const f16x8 vf = f16x8{vlo[0], vlo[1], vlo[2], vlo[3], vhi[0], vhi[1], vhi[2], vhi[3]};
 #pragma unroll
           for (int rb = 0; rb < 2; ++rb) acc_o[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[rb][s], acc_o[rb][cb], 0, 0, 0);
-          if constexpr (OSUM && cb == CB - 1) {
+          if constexpr (cb == CB - 1) {
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) l_acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[rb][s], l_acc[rb], 0, 0, 0);
-          } else if constexpr (MSUM && cb == CB - 1) {
-            rowsum_mfma16(l_acc[0], pf[0][s]);
-            rowsum_mfma16(l_acc[1], pf[1][s]);
           }
         });
       }
@@ -556,8 +519,8 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
     exp_s(R0{}, R1{});
     exp_s(R1{}, R1{});
     {
-      constexpr int NM = 2 * CB + (OSUM ? 2 : MSUM ? 4 : 0);
-      constexpr int NV = (MSUM ? 40 : 56) / NM > 0 ? (MSUM ? 40 : 56) / NM : 1;
+      constexpr int NM = 2 * CB + 2;  // MFMAs of k-step 0: PV + row sums
+      constexpr int NV = 40 / NM;     // 16 fma + 16 exp + 8 cvt of k-step 1 spread over them
       static_for<0, NM>([&](auto) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
@@ -565,10 +528,6 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
     }
     __builtin_amdgcn_sched_barrier(0);
     pv_s(R1{});
-    if constexpr (!MSUM) {
-      l_run[0] += psum[0];
-      l_run[1] += psum[1];
-    }
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -621,21 +580,14 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   float l_tot[2];
   auto row_sum = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) l_tot[rb] = OSUM ? l_acc[rb][0] : group4_sum(MSUM ? l_acc[rb][0] : l_run[rb]);
+    for (int rb = 0; rb < 2; ++rb) l_tot[rb] = l_acc[rb][0];  // every element of the all-ones block is the complete row sum
   };
   row_sum();
   {
-    // deferred fp16-overflow vote (see attn_fwd.hip): one decision per workgroup
+    // Deferred fp16-overflow vote, one decision per workgroup: an infinite P makes the row sum infinite (or NaN), whatever it
+    // does to the outputs.  The four waves share the K / V tiles and the barriers, so they redo the Q block together.
     int* flag = reinterpret_cast<int*>(smem + TILES_BYTES);
     float chk = l_tot[0] + l_tot[1];
-    if constexpr (!MSUM) {
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) chk += fabsf(acc_o[rb][cb][e]);
-    }
     const int bad = __any(!(chk < INFINITY)) ? 1 : 0;
     if (lane == 0) flag[wave] = bad;
     __syncthreads();

@@ -350,10 +350,16 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
     for (int i = lane + 64; i < nK; i += 64) ks_max = fmaxf(ks_max, ksc[i * ksc_blk]);
     ks_max = fmaxf(wave_max_nonneg(ks_max), 1e-30f);
   }
+  // wave-uniform values below are moved to SGPRs by hand (the compiler keeps uniform floats in VGPRs, and the tile loop has none
+  // to spare: left alone, the QQ instances parked 14 cold dwords in scratch)
+  auto uniform = [](float v) __attribute__((always_inline)) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+  };
+  qsc = uniform(qsc);
   const float sc_max = qsc * ks_max;
   const int gexp = (int)((__float_as_uint(1.25f * kMagic * sc_max) >> 23) & 0xff) - 127 + 1 - 21;  // log2(G)
-  const float G = __builtin_ldexpf(1.0f, gexp), invG = __builtin_ldexpf(1.0f, -gexp);
-  const float gg = __builtin_ldexpf(1.0f, gexp - 22), invg = __builtin_ldexpf(1.0f, 22 - gexp);
+  const float G = uniform(__builtin_ldexpf(1.0f, gexp)), invG = uniform(__builtin_ldexpf(1.0f, -gexp));
+  const float gg = uniform(__builtin_ldexpf(1.0f, gexp - 22)), invg = uniform(__builtin_ldexpf(1.0f, 22 - gexp));
   auto grid_up = [&](float m) __attribute__((always_inline)) { return __builtin_ceilf(m * invG) * G; };
   float sc_tab = 0.f, c0_tab = 0.f;
   auto refresh_scale_table = [&](int j0) __attribute__((always_inline)) {

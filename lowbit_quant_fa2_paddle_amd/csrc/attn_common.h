@@ -19,18 +19,26 @@ __device__ __forceinline__ f16x4 lds_read_tr16(const char* addr) {
 // The same read issued behind the compiler's back (no memory operand), for tiles that arrive by LDS-DMA: a ds_read_tr intrinsic
 // following a `buffer_load ... lds` makes the compiler wait for vmcnt(0) first - it cannot know that the DMA in flight fills the
 // OTHER buffer - which parks every wave in the middle of each tile until the prefetch has landed.  The result is valid only
-// after lds_wait_all() has been given the registers.
+// after lds_wait_keep() has been given the registers.
 template <int OFF>
 __device__ __forceinline__ f16x4 lds_read_tr16_raw(unsigned lds_addr) {
   f16x4 v;
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
   return v;
 }
-__device__ __forceinline__ void lds_wait_all(f16x4& a, f16x4& b, f16x4& c, f16x4& d, f16x4& e, f16x4& f, f16x4& g, f16x4& h) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+// wait until at most N LDS operations issued AFTER the ones that produced these registers are still in flight (LDS returns in
+// order; only valid where the wave has no other LDS / scalar-memory operation outstanding)
+template <int N>
+__device__ __forceinline__ void lds_wait_keep(f16x4& a, f16x4& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
-__device__ __forceinline__ void lds_wait_all(f16x4& a, f16x4& b, f16x4& c, f16x4& d) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+template <int N>
+__device__ __forceinline__ void lds_wait_keep(f16x4& a, f16x4& b, f16x4& c, f16x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_keep(f16x4& a, f16x4& b, f16x4& c, f16x4& d, f16x4& e, f16x4& f, f16x4& g, f16x4& h) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "n"(N));
 }
 __device__ __forceinline__ unsigned lds_offset_of(const void* shared_ptr) {
   return (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char*)shared_ptr;

@@ -30,9 +30,11 @@ namespace lbfa {
 
 constexpr float kLazyThr = 8.0f;  // exact paths move the softmax reference only when a row max outgrows it by more than 2^8
 constexpr bool kPingPong = true;  // every other round of Q blocks walks the key tiles backwards (L2 reuse, see attn_fwd.hip)
-// channel blocks per batch of V^T reads (4 registers each): 4 costs the D = 64 loop a scratch reload per tile (168 registers),
-// 2 costs D = 128 1.5 % (one more LDS round trip per k-step)
-template <int D> constexpr int kVBatch = (D == 64) ? 2 : 4;
+// V^T fragments are read in batches of kVBatch channel blocks (4 registers each), kVAhead batches ahead of the MFMAs that use
+// them (kVAhead + 1 register sets).  Measured (S16K / D128 / C3): one block ahead at 1 / 2 blocks per batch +1 / +3..5 / +2 % over
+// un-pipelined batches of 2 / 4; two or three batches ahead, or bigger batches (spills), no better.
+template <int D> constexpr int kVBatch = (D == 64) ? 1 : 2;
+constexpr int kVAhead = 1;
 
 template <int RB>
 __device__ __forceinline__ int kx16(int row) {  // K-tile 16-byte chunk swizzle, rows of RB bytes
@@ -466,28 +468,45 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
 #pragma unroll
         for (int e = 0; e < 4; ++e) pf[rb][s][4 * k2 + e] = (_Float16)x[rb][2 * s + k2][e];
     };
-    // O^T += V^T P^T for one k-step: every V^T fragment is read once and serves both row blocks
+    // O^T += V^T P^T.  The V^T fragments of a tile are read in NBT = 2 CB / VG batches of VG channel blocks (every fragment
+    // serves both row blocks); batch b + VD is requested before the MFMAs of batch b are issued (VD + 1 register sets, counted
+    // lgkmcnt waits: LDS returns in order and the wave has no other LDS traffic in this phase), the first VD batches of the tile
+    // before the exponentials.
+    constexpr int VG = kVBatch<D>;
+    constexpr int NQ = CB / VG, NBT = 2 * NQ;
+    constexpr int VD = kVAhead;  // batches requested ahead of the one whose MFMAs are being issued
+    f16x4 vb_lo[VD + 1][VG], vb_hi[VD + 1][VG];
+    auto v_issue = [&](auto b_tag) __attribute__((always_inline)) {
+      constexpr int bb = decltype(b_tag)::value, s = bb / NQ, c0 = VG * (bb % NQ), slot = bb % (VD + 1);
+      constexpr int off = BUF * VBYTES + (32 * s) * (2 * D);
+      static_for<0, VG>([&](auto c) {
+        constexpr int ci = decltype(c)::value;
+        vb_lo[slot][ci] = lds_read_tr16_raw<off>(vf_addr[c0 + ci]);
+        vb_hi[slot][ci] = lds_read_tr16_raw<off + 16 * 2 * D>(vf_addr[c0 + ci]);
+      });
+    };
+    auto v_use = [&](auto b_tag) __attribute__((always_inline)) {
+      constexpr int bb = decltype(b_tag)::value, s = bb / NQ, c0 = VG * (bb % NQ), slot = bb % (VD + 1);
+      constexpr int AHEAD = (NBT - 1 - bb) < VD ? (NBT - 1 - bb) : VD;
+      constexpr int KEEP = 2 * VG * AHEAD;  // reads of the following batches may stay in flight
+      if constexpr (VG == 4) lds_wait_keep<KEEP>(vb_lo[slot][0], vb_hi[slot][0], vb_lo[slot][1], vb_hi[slot][1], vb_lo[slot][2], vb_hi[slot][2], vb_lo[slot][3], vb_hi[slot][3]);
+      else if constexpr (VG == 2) lds_wait_keep<KEEP>(vb_lo[slot][0], vb_hi[slot][0], vb_lo[slot][1], vb_hi[slot][1]);
+      else lds_wait_keep<KEEP>(vb_lo[slot][0], vb_hi[slot][0]);
+      static_for<0, VG>([&](auto c) {
+        constexpr int ci = decltype(c)::value, cb = c0 + ci;
+        const f16x4 lo = vb_lo[slot][ci], hi = vb_hi[slot][ci];
+        const f16x8 vf = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) acc_o[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[rb][s], acc_o[rb][cb], 0, 0, 0);
+      });
+    };
     auto pv_s = [&](auto s_tag) __attribute__((always_inline)) {
       constexpr int s = decltype(s_tag)::value;
       if constexpr (VRAW) {
-        constexpr int VG = kVBatch<D>;
-        static_for<0, CB / VG>([&](auto q4) {
-          constexpr int c0 = VG * decltype(q4)::value;
-          constexpr int off = BUF * VBYTES + (32 * s) * (2 * D);
-          f16x4 vlo[VG], vhi[VG];
-          static_for<0, VG>([&](auto c) {
-            constexpr int ci = decltype(c)::value;
-            vlo[ci] = lds_read_tr16_raw<off>(vf_addr[c0 + ci]);
-            vhi[ci] = lds_read_tr16_raw<off + 16 * 2 * D>(vf_addr[c0 + ci]);
-          });
-          if constexpr (VG == 4) lds_wait_all(vlo[0], vhi[0], vlo[1], vhi[1], vlo[2], vhi[2], vlo[3], vhi[3]);
-          else lds_wait_all(vlo[0], vhi[0], vlo[1], vhi[1]);
-          static_for<0, VG>([&](auto c) {
-            constexpr int ci = decltype(c)::value, cb = c0 + ci;
-            const f16x8 vf = f16x8{vlo[ci][0], vlo[ci][1], vlo[ci][2], vlo[ci][3], vhi[ci][0], vhi[ci][1], vhi[ci][2], vhi[ci][3]};
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) acc_o[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[rb][s], acc_o[rb][cb], 0, 0, 0);
-          });
+        static_for<0, NQ>([&](auto q) {
+          constexpr int bb = s * NQ + decltype(q)::value;
+          if constexpr (bb + VD < NBT) v_issue(std::integral_constant<int, bb + VD>{});
+          v_use(std::integral_constant<int, bb>{});
         });
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) l_acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[rb][s], l_acc[rb], 0, 0, 0);
@@ -515,6 +534,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
       return;
     }
     if constexpr (EXACT) update_reference(THR);
+    if constexpr (VRAW) static_for<0, (VD < NBT ? VD : NBT)>([&](auto b0) { v_issue(b0); });
     c1[0] = c0 - m_run[0];  // exact (grid argument); +inf while m_run = -inf
     c1[1] = c0 - m_run[1];
     exp_s(R0{}, R0{});

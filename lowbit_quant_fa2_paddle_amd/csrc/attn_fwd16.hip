@@ -1,9 +1,9 @@
 // Fused low-bit FlashAttention-2 forward for gfx950, fp16-P variants, on the 16x16 MFMA shapes
 // (v_mfma_i32_16x16x64_i8 for QK^T, v_mfma_f32_16x16x32_f16 for PV).
 //
-// Same operator, same tiling in the large (one workgroup = 4 waves = one 128-row Q block, 32 query rows per wave, 64-key K / V
-// tiles by LDS-DMA, double-buffered, lazy softmax reference with a deferred overflow vote, see attn_fwd.hip) - but every matrix
-// product is cut into 16x16 output blocks.  Why: on this part the same FLOPs cost fewer cycles AND hold a higher clock on the
+// Same operator and the same tiling in the large as the fp8 kernel (attn_fwd.hip): one workgroup = 4 waves = one 128-row Q block,
+// 32 query rows per wave, 64-key K / V tiles by LDS-DMA, double-buffered, scores biased by 1.5 * 2^23 so the int32 accumulator
+// bits are floats, dequantisation folded into the exp2 argument - but every matrix product is cut into 16x16 output blocks.  Why: on this part the same FLOPs cost fewer cycles AND hold a higher clock on the
 // 16x16 shapes (tools/ubench_tile.hip: the MFMA + softmax stream of one tile without memory traffic takes 290 ns per wave
 // and SIMD on them against 400 ns on the 32x32 shapes: -14 % cycles, +19 % clock; MI355X_MICROARCH.md "DVFS give-back" item 7).
 // At D = 64 one i8 MFMA spans the whole head dim (K = 64): the eight score MFMAs of a tile are independent - no accumulate
@@ -18,8 +18,13 @@
 //                 A = V^T fragment with the SAME key order: two ds_read_b64_tr_b16 (rows 32 s + 4 g + {0..3} and + 16) of the
 //                 row-major V tile; one fragment serves both row blocks
 //                 C: lane holds, for its query, channels 16 cb + 4 g + {0..3}
-//   A query row's scores live in four lanes (g = 0..3): row max / row sum need two cross-group steps, which only the exact
-//   path (masked tiles, re-run) and the epilogue take.
+//   A query row's scores live in four lanes (g = 0..3): a row max needs two cross-group steps, which only the exact path (masked
+//   tiles, re-run) takes; the row sums come out of one more PV block against an all-ones V^T (every lane gets the complete sum).
+// Lazy softmax reference with a DEFERRED overflow check: the first tile of a Q block sets the reference m (exact row max, no PV),
+// every later unmasked tile is exponentiated against m AS IT STANDS - any reference within 2^15 of the row max is as good as the
+// max (P is floating point, fp32 accumulate) - and nothing inside the tile loop looks at the result.  A row whose scores outgrow
+// m by more than 2^16 overflows fp16 P: the infinity reaches its row sum, the workgroup votes ONCE after the loop and, if any row
+// is not finite, redoes the Q block with the exact row max in every tile (run_tiles(Yes), the code path of the masked tiles).
 // LDS images (checked conflict-free by enumeration of the hardware's lane groups):
 //   K tile [64][RB bytes]: 16-byte chunk c of row r at c ^ kx16(r), kx16 = (r >> 1) & 3 | r & 7 | r & 15 for RB = 64 | 128 | 256
 //   V tile [64][2 D bytes]: 32-byte block c of row r at c ^ vx16(r), vx16 = (r >> 1) & 3 (D = 64) | r & 7 (D = 128)

@@ -6,17 +6,8 @@
 
 namespace lbfa {
 
-typedef __fp16 hf16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
-typedef __attribute__((address_space(3))) hf16x4* lds_hf16x4_ptr;
-
-// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of 16-bit elements, delivered
-// column-major (lane i gets column i of the 4 rows).  EXEC must be all ones.
-__device__ __forceinline__ f16x4 lds_read_tr16(const char* addr) {
-  const hf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hf16x4_ptr)(addr));
-  return __builtin_bit_cast(f16x4, v);
-}
-
-// The same read issued behind the compiler's back (no memory operand), for tiles that arrive by LDS-DMA: a ds_read_tr intrinsic
+// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of 16-bit elements, delivered column-major (lane i gets column
+// i of the 4 rows).  EXEC must be all ones.  Issued behind the compiler's back (inline asm, no memory operand): the intrinsic form
 // following a `buffer_load ... lds` makes the compiler wait for vmcnt(0) first - it cannot know that the DMA in flight fills the
 // OTHER buffer - which parks every wave in the middle of each tile until the prefetch has landed.  The result is valid only
 // after lds_wait_keep() has been given the registers.
@@ -49,11 +40,6 @@ __device__ __forceinline__ int kx(int row) {  // K-tile 16-B chunk swizzle for r
   if constexpr (RB == 64) return (row >> 2) & 3;
   else if constexpr (RB == 128) return (row >> 1) & 7;
   else return row & 15;
-}
-template <int D>
-__device__ __forceinline__ int vx(int row) {  // V-tile 64-B chunk swizzle
-  if constexpr (D == 64) return (row >> 1) & 1;
-  else return row & 3;
 }
 
 __device__ __forceinline__ float half_swap_max(float x) {

@@ -317,9 +317,8 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) vf_base[cb] = 2 * KBYTES + vr * (2 * D) + ((cb ^ vx16<D>(vr)) << 5) + (i16 & 3) * 8;
   }
-  // V fragments of DMA-fed tiles are read by hand-issued ds_read_b64_tr_b16 (attn_common.h, lds_read_tr16_raw): the compiler then
-  // orders nothing against the prefetch in flight, so the tile loop waits for it itself - vmcnt(0) in front of each barrier
-  constexpr bool VRAW = DMA_V;
+  // V fragments are read by hand-issued ds_read_b64_tr_b16 (attn_common.h, lds_read_tr16_raw): the compiler then orders nothing
+  // against the LDS-DMA prefetch in flight, so the tile loop waits for it itself - vmcnt(0) in front of each barrier
   unsigned vf_addr[CB];
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) vf_addr[cb] = lds_offset_of(smem) + vf_base[cb];
@@ -384,7 +383,6 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
     constexpr bool EXACT = decltype(exact_tag)::value || MASKED;
     constexpr bool PRIME = decltype(prime_tag)::value;
     const char* kbuf = smem + BUF * KBYTES;
-    const char* vbuf = smem + BUF * VBYTES;
     float sc, c0;
     if constexpr (QK16) {
       sc = p.qk_scale;
@@ -507,28 +505,13 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
     };
     auto pv_s = [&](auto s_tag) __attribute__((always_inline)) {
       constexpr int s = decltype(s_tag)::value;
-      if constexpr (VRAW) {
-        static_for<0, NQ>([&](auto q) {
-          constexpr int bb = s * NQ + decltype(q)::value;
-          if constexpr (bb + VD < NBT) v_issue(std::integral_constant<int, bb + VD>{});
-          v_use(std::integral_constant<int, bb>{});
-        });
+      static_for<0, NQ>([&](auto q) {
+        constexpr int bb = s * NQ + decltype(q)::value;
+        if constexpr (bb + VD < NBT) v_issue(std::integral_constant<int, bb + VD>{});
+        v_use(std::integral_constant<int, bb>{});
+      });
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) l_acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[rb][s], l_acc[rb], 0, 0, 0);
-      } else {
-        static_for<0, CB>([&](auto c) {
-          constexpr int cb = decltype(c)::value;
-          const f16x4 vlo = lds_read_tr16(vbuf + vf_base[cb] + (32 * s) * (2 * D));
-          const f16x4 vhi = lds_read_tr16(vbuf + vf_base[cb] + (32 * s + 16) * (2 * D));
-          const f16x8 vf = f16x8{vlo[0], vlo[1], vlo[2], vlo[3], vhi[0], vhi[1], vhi[2], vhi[3]};
-#pragma unroll
-          for (int rb = 0; rb < 2; ++rb) acc_o[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[rb][s], acc_o[rb][cb], 0, 0, 0);
-          if constexpr (cb == CB - 1) {
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) l_acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[rb][s], l_acc[rb], 0, 0, 0);
-          }
-        });
-      }
+      for (int rb = 0; rb < 2; ++rb) l_acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[rb][s], l_acc[rb], 0, 0, 0);
     };
     using R0 = std::integral_constant<int, 0>;
     using R1 = std::integral_constant<int, 1>;
@@ -539,7 +522,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
       return;
     }
     if constexpr (EXACT) update_reference(THR);
-    if constexpr (VRAW) static_for<0, (VD < NBT ? VD : NBT)>([&](auto b0) { v_issue(b0); });
+    static_for<0, (VD < NBT ? VD : NBT)>([&](auto b0) { v_issue(b0); });
     c1[0] = c0 - m_run[0];  // exact (grid argument); +inf while m_run = -inf
     c1[1] = c0 - m_run[1];
     exp_s(R0{}, R0{});

@@ -17,8 +17,10 @@ __device__ __forceinline__ f16x4 lds_read_tr16_raw(unsigned lds_addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
   return v;
 }
-// wait until at most N LDS operations issued AFTER the ones that produced these registers are still in flight (LDS returns in
-// order; only valid where the wave has no other LDS / scalar-memory operation outstanding)
+// Wait until at most N operations issued AFTER the reads that produced these registers are still in flight.  N = the reads
+// this wave has requested since (LDS returns in order).  Anything else the compiler has outstanding on the same counter (its own
+// LDS reads, scalar loads - which may return out of order) only makes the wait stricter: the count cannot fall to N while one
+// of the older reads is pending, because N younger LDS reads stand behind it.
 template <int N>
 __device__ __forceinline__ void lds_wait_keep(f16x4& a, f16x4& b) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));

@@ -7,7 +7,7 @@ name=$1; extra=$2
 C=lowbit_quant_fa2_paddle_amd/csrc
 mkdir -p variants /tmp/lbfa_exp_$name
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize $extra"
-/opt/rocm/bin/hipcc $FLAGS -DLBFA_D16=64 -c $C/attn_fwd16.hip -o /tmp/lbfa_exp_$name/attn_fwd16_d64.o &
+/opt/rocm/bin/hipcc $FLAGS -mllvm -enable-post-misched=0 -DLBFA_D16=64 -c $C/attn_fwd16.hip -o /tmp/lbfa_exp_$name/attn_fwd16_d64.o &
 p1=$!
 /opt/rocm/bin/hipcc $FLAGS -DLBFA_D16=128 -c $C/attn_fwd16.hip -o /tmp/lbfa_exp_$name/attn_fwd16_d128.o &
 p2=$!

@@ -14,7 +14,8 @@ for f in lbfa_api quant_kernels attn_fwd; do
   pids="$pids $!"
 done
 for d in 64 128; do  # attn_fwd16.hip: one translation unit per head dim (as the Makefile does)
-  /opt/rocm/bin/hipcc $FLAGS -DLBFA_D16=$d -c $C/attn_fwd16.hip -o /tmp/lbfa_var_$name/attn_fwd16_d$d.o &
+  f16=""; [ $d = 64 ] && f16="-mllvm -enable-post-misched=0"  # as the Makefile
+  /opt/rocm/bin/hipcc $FLAGS $f16 -DLBFA_D16=$d -c $C/attn_fwd16.hip -o /tmp/lbfa_var_$name/attn_fwd16_d$d.o &
   pids="$pids $!"
 done
 for p in $pids; do wait $p; done   # set -e: a failed compile stops here

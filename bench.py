@@ -97,18 +97,30 @@ def cpu_baseline(B, H, S, D, causal, budget_s=12.0):
                       f"(src/core.py:46-69 restated, {impl}), {el:.1f} s"}
 
 
-def make_inputs(torch, dev, B, H, Hkv, S, D, layout, seed, dist_kind="normal"):
+def make_inputs(torch, dev, B, H, Hkv, S, D, layout, seed, dist_kind="normal", dtype="fp16"):
+    """normal: q,k,v ~ N(0,1) (example/test_sageattn_operator.py:43-52).  randint: the reference's bench distribution
+    q,k = randint(-100,100), v ~ N(0,1) (utils/benchmark.py:215-230) - one-hot softmax rows.  normal_exact: N(0,1) with a step
+    in channel 0 that puts the first 64 keys 2^23 below all later ones for every query - every Q block overflows its lazy
+    pass at the first vote and runs the exact path (row max per tile) over otherwise N(0,1) scores."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
+    tdt = torch.float16 if dtype == "fp16" else torch.bfloat16
     shp_q = (B, H, S, D) if layout == "HND" else (B, S, H, D)
     shp_k = (B, Hkv, S, D) if layout == "HND" else (B, S, Hkv, D)
-    if dist_kind == "normal":
-        q = torch.randn(shp_q, generator=g, device=dev, dtype=torch.float32).half()
-        k = torch.randn(shp_k, generator=g, device=dev, dtype=torch.float32).half()
+    if dist_kind in ("normal", "normal_exact"):
+        q = torch.randn(shp_q, generator=g, device=dev, dtype=torch.float32)
+        k = torch.randn(shp_k, generator=g, device=dev, dtype=torch.float32)
+        if dist_kind == "normal_exact":
+            a = 8.0 * (D / 64.0) ** 0.5
+            q[..., 0] += a
+            ks = k if layout == "HND" else k.transpose(1, 2)
+            ks[:, :, :64, 0] -= a
+            ks[:, :, 64:, 0] += a
+        q, k = q.to(tdt), k.to(tdt)
     else:
-        q = torch.randint(-100, 100, shp_q, generator=g, device=dev).half()
-        k = torch.randint(-100, 100, shp_k, generator=g, device=dev).half()
-    v = torch.randn(shp_k, generator=g, device=dev, dtype=torch.float32).half()
+        q = torch.randint(-100, 100, shp_q, generator=g, device=dev).to(tdt)
+        k = torch.randint(-100, 100, shp_k, generator=g, device=dev).to(tdt)
+    v = torch.randn(shp_k, generator=g, device=dev, dtype=torch.float32).to(tdt)
     return q, k, v
 
 
@@ -123,13 +135,13 @@ def time_fn(torch, f, iters, warmup=2):
     return (time.perf_counter() - t0) / iters
 
 
-def sweep_point(torch, lb, lib, dev, name, spec, iters, refs=True):
-    """One row of the `sweep` table: whole operator + attention kernel (library-recorded HIP events) + the two fp16
+def sweep_point(torch, lb, lib, dev, name, spec, iters, refs=True, dist_kind="normal", dtype="fp16"):
+    """One row of the `sweep` table: whole operator + attention kernel (library-recorded HIP events) + the two 16-bit
     comparison points on the same inputs."""
     api, B, H, Hkv, S, D, layout, causal, extra, desc = spec
     fn = {"int8_fp16": lb.lowbit_fa_qk_int8_pv_fp16_triton, "int4_fp16": lb.lowbit_fa_qk_int4_pv_fp16_triton,
           "int8_fp8": lb.lowbit_fa_qk_int8_pv_fp8_cuda}[api]
-    q, k, v = make_inputs(torch, dev, B, H, Hkv, S, D, layout, 99)
+    q, k, v = make_inputs(torch, dev, B, H, Hkv, S, D, layout, 99, dist_kind, dtype)
     f = lambda: fn(q, k, v, tensor_layout=layout, is_causal=causal, **extra)
     flops = 4.0 * B * H * D * S * S / (2 if causal else 1)
     for _ in range(3):
@@ -146,10 +158,13 @@ def sweep_point(torch, lb, lib, dev, name, spec, iters, refs=True):
         f()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
-    kms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / iters
+    ks = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    kms = sum(ks) / iters
     peak = PEAK_I8_TF if api == "int8_fp8" else PEAK_MIX_TF
     row = {"workload": name, "api": api, "B": B, "H": H, "S": S, "D": D, "layout": layout, "causal": causal,
+           "dist": dist_kind, "dtype": dtype,
            "ms": round(dt * 1e3, 4), "tflops": round(flops / dt / 1e12, 1), "kernel_ms": round(kms, 4),
+           "kernel_ms_median": round(ks[len(ks) // 2], 4),
            "kernel_tflops": round(flops / (kms * 1e-3) / 1e12, 1), "frac": round(flops / (kms * 1e-3) / 1e12 / peak, 4)}
     if refs and api != "int8_fp8":
         try:
@@ -174,14 +189,23 @@ def run_sweep(torch, lb, lib, dev):
     # one throw-away point first: library / allocator / flash-backend initialisation must not land in the first row
     sweep_point(torch, lb, lib, dev, "warm-up", ("int8_fp16", 1, 8, 8, 2048, 64, "HND", False, {}, "warm-up"), 3)
     sweep_point(torch, lb, lib, dev, "warm-up", ("int8_fp16", 1, 8, 8, 2048, 128, "HND", True, {}, "warm-up"), 3)
+    its = {4096: 40, 8192: 16, 16384: 6, 32768: 3}
     for D in (64, 128):
         for causal in (False, True):
             for S in (4096, 8192, 16384, 32768):
                 nm = f"int8_fp16 S{S // 1024}K D{D}{' causal' if causal else ''}"
                 spec = ("int8_fp16", 4, 32, 32, S, D, "HND", causal, {}, nm)
-                rows.append(sweep_point(torch, lb, lib, dev, nm, spec, {4096: 40, 8192: 16, 16384: 6, 32768: 3}[S]))
+                rows.append(sweep_point(torch, lb, lib, dev, nm, spec, its[S]))
     for nm in ("c3", "c4", "c4m", "c5"):
         rows.append(sweep_point(torch, lb, lib, dev, nm, WORKLOADS[nm], 3, refs=(nm != "c5")))
+    # the same shapes on other inputs: the reference's own bench distribution (every Q block leaves the lazy pass at its first
+    # vote), N(0,1) scores forced onto the exact path, and bf16 storage (V is converted to fp16 as src/core.py:307-308 does)
+    for dist_kind in ("randint", "normal_exact"):
+        for nm, S, it in (("c2", 4096, 40), ("s16k", 16384, 6), ("c3", 16384, 3)):
+            rows.append(sweep_point(torch, lb, lib, dev, f"{nm} {dist_kind}", WORKLOADS[nm], it, refs=False, dist_kind=dist_kind))
+    for nm, spec, it in (("c2 bf16", WORKLOADS["c2"], 40), ("c3 bf16", WORKLOADS["c3"], 3),
+                         ("int8_fp16 S8K D128 bf16", ("int8_fp16", 4, 32, 32, 8192, 128, "HND", False, {}, ""), 16)):
+        rows.append(sweep_point(torch, lb, lib, dev, nm, spec, it, refs=False, dtype="bf16"))
     torch.cuda.empty_cache()
     return rows
 
@@ -205,13 +229,17 @@ def c5_strong(torch, lb, dev, world, rank, distributed, dist, share, steps=3):
     if distributed:
         dist.barrier()
     el = (time.perf_counter() - t0) / steps
+    rank_ms = [round(el * 1e3, 3)]
     if distributed:
         tt = torch.tensor([el], device="cpu" if share else dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)  # per-rank times: a future SCALE record shows imbalance between the shards
+        rank_ms = [round(float(x.item()) * 1e3, 3) for x in allt]
+        el = max(float(x.item()) for x in allt)
     flops = 4.0 * Bg * H * D * S * S
     res = {"workload": "qk_int8_pv_fp8 B32 H32 S32768 D128 (BASELINE configs[4]), batch split over the ranks, strong scaling",
-           "B_per_gpu": B, "ms": round(el * 1e3, 3), "tflops_total": round(flops / el / 1e12, 1), "steps": steps}
+           "B_per_gpu": B, "ms": round(el * 1e3, 3), "tflops_total": round(flops / el / 1e12, 1), "steps": steps,
+           "rank_ms_min": min(rank_ms), "rank_ms_max": max(rank_ms), "rank_ms": rank_ms}
     if distributed:
         from lowbit_quant_fa2_paddle_amd import dist as lbdist
         try:  # the gather is reported, never part of `value`: a backend that cannot do it must not lose the bench line
@@ -238,11 +266,17 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--dist", default="normal", choices=["normal", "randint"],
+    ap.add_argument("--dist", default="normal", choices=["normal", "randint", "normal_exact"],
                     help="normal: q,k,v ~ N(0,1) (example/test_sageattn_operator.py:43-52); randint: the reference "
-                         "bench distribution q,k = randint(-100,100), v ~ N(0,1) (utils/benchmark.py:215-230)")
+                         "bench distribution q,k = randint(-100,100), v ~ N(0,1) (utils/benchmark.py:215-230); "
+                         "normal_exact: N(0,1) scores forced onto the exact softmax path (see make_inputs)")
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"], help="storage dtype of q, k, v and o")
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                    help="un-counted operator launches for at least this long BEFORE the --warmup steps: the first launches "
+                         "of a process run slow (clock ramp, code-object and allocator first touch), and 5 warm-up steps of "
+                         "0.5 ms do not cover that")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel-timer-every", type=int, default=4,
+    ap.add_argument("--kernel-timer-every", type=int, default=2,
                     help="bracket the attention kernel of every N-th timed step with HIP events (each pair costs the step ~6 us of "
                          "queue barriers: timing every step would tax `value` by 1 %%)")
     ap.add_argument("--no-fa2", action="store_true", help="skip the torch flash-attention comparison point")
@@ -281,7 +315,7 @@ def main():
     fn = {"int8_fp16": lb.lowbit_fa_qk_int8_pv_fp16_triton, "int4_fp16": lb.lowbit_fa_qk_int4_pv_fp16_triton,
           "int8_fp8": lb.lowbit_fa_qk_int8_pv_fp8_cuda}[api]
 
-    q, k, v = make_inputs(torch, dev, B, H, Hkv, S, D, layout, 1234 + rank, args.dist)
+    q, k, v = make_inputs(torch, dev, B, H, Hkv, S, D, layout, 1234 + rank, args.dist, args.dtype)
 
     def step():
         return fn(q, k, v, tensor_layout=layout, is_causal=causal, **extra)
@@ -306,6 +340,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # stated pre-warm (not part of --warmup, not timed): operator launches until `prewarm_ms` of wall time have passed
+    torch.cuda.synchronize()
+    tp0, prewarm_steps = time.perf_counter(), 0
+    while (time.perf_counter() - tp0) * 1e3 < args.prewarm_ms:
+        for _ in range(8):
+            o = step()
+        torch.cuda.synchronize()
+        prewarm_steps += 8
     for _ in range(args.warmup):
         o = step()
     barrier()
@@ -411,17 +453,20 @@ def main():
             "scaling": "weak",
             "vs_baseline": round(value / PUBLISHED[args.workload], 3) if (args.workload in PUBLISHED and world == 1) else None,
             "dtype": "int8 (QK^T) + fp16 (PV), fp32 softmax/accumulate" if api != "int8_fp8" else "int8 (QK^T) + fp8 e4m3 (PV), fp32 softmax/accumulate",
-            "data": f"synthetic, {'q,k,v ~ N(0,1)' if args.dist == 'normal' else 'q,k = randint(-100,100), v ~ N(0,1)'} fp16, resident in HBM",
+            "data": f"synthetic, {({'normal': 'q,k,v ~ N(0,1)', 'randint': 'q,k = randint(-100,100), v ~ N(0,1)', 'normal_exact': 'N(0,1) with the first key tile 2^23 below the rest (exact softmax path)'})[args.dist]} {args.dtype}, resident in HBM",
             "config": {"workload": desc, "global_batch": B * world, "heads": H, "seq_len": S, "head_dim": D,
                        "layout": layout, "causal": causal, "parallelism": f"batch-shard x{world} (no data-path collective)",
                        "timed": "whole operator: smooth-K mean + per-block quant(Q,K) + fused attention",
                        "kernel_only_tflops_per_gpu": round(achieved, 2), "fwd_latency_ms": round(ms_per_step, 4),
+                       "prewarm": f"{prewarm_steps} un-counted operator launches (>= {args.prewarm_ms:.0f} ms) before the {args.warmup} warm-up steps",
+                       "kernel_timer": f"HIP events around the attention launch of every {max(1, args.kernel_timer_every)}-th timed step: {len(kern_all)} samples",
                        "baseline_note": "vs_baseline = value / reference's published kernel-only TFLOP/s on unnamed NVIDIA hardware (BASELINE.md)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "frac_of_fp16_roof": round(achieved / PEAK_F16_TF, 4),
                          "hbm_GBps": (round(traffic / (kern_ms * 1e-3) / 1e9, 1) if (traffic and kern_ms > 0) else None),
                          "kernel": ("attn_fwd_kernel" if api == "int8_fp8" else "attn_fwd16_kernel"), "kernel_ms": round(kern_ms, 4), "kernel_ms_median": round(kern_med, 4),
+                         "achieved_median": round(flops_rank / (kern_med * 1e-3) / 1e12, 2) if kern_med > 0 else None,
                          "peak_note": ("int8 MFMA for QK^T and block-scaled e4m3 MFMA for PV: 5000 both" if api == "int8_fp8" else
                                        "mixed roof 1/(0.5/5000 + 0.5/2500): half the FLOPs int8 MFMA, half fp16 MFMA")},
             "cpu_baseline": cpu,

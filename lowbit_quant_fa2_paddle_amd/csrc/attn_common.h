@@ -54,6 +54,48 @@ __device__ __forceinline__ float half_swap_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// ---- reductions over the four lanes l, l + 16, l + 32, l + 48 (one lane per 16-lane row) without the LDS crossbar -----------
+// v_permlane16_swap exchanges the odd rows of its first operand with the even rows of the second, v_permlane32_swap the two
+// halves: after each step both partners hold both values.  Two VALU instructions per step instead of a ds_bpermute round trip.
+__device__ __forceinline__ float rows4_sum(float x) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+// "Order keys": the scores of the int8 product are the accumulator bits of kMagic + s, which compare like the integers s as
+// signed int32 (-inf = 0xFF800000 sorts below all of them) - integer maxima need no NaN canonicalisation in front; the fp32
+// scores of the un-quantised product compare as floats (v_max*_f32 by hand: the compiler would put a canonicalising v_max in
+// front of an fmaxf on MFMA output).
+template <bool AS_INT>
+__device__ __forceinline__ float key_max(float a, float b) {
+  if constexpr (AS_INT) {
+    const int x = __float_as_int(a), y = __float_as_int(b);
+    return __int_as_float(x > y ? x : y);
+  } else {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+  }
+}
+template <bool AS_INT>
+__device__ __forceinline__ float key_max3(float a, float b, float c) {
+  if constexpr (AS_INT) {
+    return key_max<true>(key_max<true>(a, b), c);  // selected as v_max3_i32
+  } else {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+  }
+}
+template <bool AS_INT>
+__device__ __forceinline__ float rows4_key_max(float x) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = key_max<AS_INT>(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return key_max<AS_INT>(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 // Raw buffer resource over [base, base+bytes): out-of-range loads return 0 (hardware bounds check).
 // Built from kernel arguments and blockIdx-derived scalars only, so it stays in SGPRs.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {

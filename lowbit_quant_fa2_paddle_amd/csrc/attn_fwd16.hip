@@ -34,6 +34,10 @@
 namespace lbfa {
 
 constexpr float kLazyThr = 8.0f;  // exact paths move the softmax reference only when a row max outgrows it by more than 2^8
+#ifndef LBFA_DEAD_SKIP
+#define LBFA_DEAD_SKIP 0
+#endif
+constexpr float kDeadArg = -26.0f;  // exp2 arguments below this give P < 2^-25, which rounds to +0 in fp16
 constexpr bool kPingPong = true;  // every other round of Q blocks walks the key tiles backwards (L2 reuse, see attn_fwd.hip)
 // V^T fragments are read in batches of kVBatch channel blocks (4 registers each), kVAhead batches ahead of the MFMAs that use
 // them (kVAhead + 1 register sets).  Measured (S16K / D128 / C3): one block ahead at 1 / 2 blocks per batch +1 / +3..5 / +2 % over
@@ -51,15 +55,6 @@ template <int D>
 __device__ __forceinline__ int vx16(int row) {  // V-tile 32-byte block swizzle
   if constexpr (D == 64) return (row >> 1) & 3;
   else return row & 7;
-}
-// sum / max over the four lanes l, l + 16, l + 32, l + 48 that share a query row
-__device__ __forceinline__ float group4_sum(float x) {
-  x += __shfl_xor(x, 16, 64);
-  return x + __shfl_xor(x, 32, 64);
-}
-__device__ __forceinline__ float group4_max(float x) {
-  x = fmaxf(x, __shfl_xor(x, 16, 64));
-  return fmaxf(x, __shfl_xor(x, 32, 64));
 }
 #if defined(LBFA_STAMPS16) && LBFA_D16 == 64  // diagnostic build only, D = 64 unit (tools/stamps.py): s_memtime at six points of a workgroup's life, wave 0 lane 0
 __device__ long long g_stamps16[8192 * 8];
@@ -252,7 +247,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
               dot += xv[e] * load_cvt<OT>((unsigned short)((e & 1) ? (vraw[e >> 1] >> 16) : (vraw[e >> 1] & 0xffffu)));
           }
         }
-      row_corr[rb] = load_cvt<OT>(store_cvt<OT>(group4_sum(dot)));  // rounded to the storage dtype (src/core.py:294-304)
+      row_corr[rb] = load_cvt<OT>(store_cvt<OT>(rows4_sum(dot)));  // rounded to the storage dtype (src/core.py:294-304)
     }
     amax = wave_max_nonneg(amax);
     LBFA_STAMP(6);
@@ -432,27 +427,32 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
           x[rb][kb][e] = tv;
         }
     };
-    auto update_reference = [&](float thr) __attribute__((always_inline)) {
+    // Lane-partial maximum of the 16 scores of a row block, as an order key (attn_common.h): 7 v_max3 + 1 v_max.
+    auto lane_max = [&](int rb) __attribute__((always_inline)) {
+      float m = key_max3<!QK16>(x[rb][0][0], x[rb][0][1], x[rb][0][2]);
+      m = key_max3<!QK16>(m, x[rb][0][3], x[rb][1][0]);
+      m = key_max3<!QK16>(m, x[rb][1][1], x[rb][1][2]);
+      m = key_max3<!QK16>(m, x[rb][1][3], x[rb][2][0]);
+      m = key_max3<!QK16>(m, x[rb][2][1], x[rb][2][2]);
+      m = key_max3<!QK16>(m, x[rb][2][3], x[rb][3][0]);
+      m = key_max3<!QK16>(m, x[rb][3][1], x[rb][3][2]);
+      return key_max<!QK16>(m, x[rb][3][3]);
+    };
+    // Move the softmax reference of row block rb up to this tile's row max where a row outgrew it by more than thr, rescaling
+    // what has been accumulated against the old one (the rare path: cross-lane maximum, grid rounding, O-wide multiply).
+    auto raise_reference = [&](int rb, float pm, float thr) __attribute__((always_inline)) {
+      const float tmax = rows4_key_max<!QK16>(pm);
+      const float xmax = __builtin_fmaf(tmax, sc, c0);
+      const float m_cand = fmaxf(m_run[rb], QK16 ? xmax : grid_up(xmax));
+      if (__any(m_cand > m_run[rb] + thr)) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_cand);  // m_run = -inf -> 0
+        m_run[rb] = m_cand;
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        float tmax = -INFINITY;
+        for (int e = 0; e < 4; ++e) l_acc[rb][e] *= alpha;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) tmax = fmaxf(tmax, x[rb][kb][e]);
-        tmax = group4_max(tmax);
-        const float xmax = __builtin_fmaf(tmax, sc, c0);
-        const float m_cand = fmaxf(m_run[rb], QK16 ? xmax : grid_up(xmax));
-        if (__any(m_cand > m_run[rb] + thr)) {
-          const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_cand);  // m_run = -inf -> 0
-          m_run[rb] = m_cand;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) l_acc[rb][e] *= alpha;
-#pragma unroll
-          for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc_o[rb][cb][e] *= alpha;
-        }
+          for (int e = 0; e < 4; ++e) acc_o[rb][cb][e] *= alpha;
       }
     };
     f16x8 pf[2][2];  // [row block][k-step of 32 keys]
@@ -518,34 +518,64 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
 
     static_for<0, 4>([&](auto kb) { compute_scores(kb); });
     if constexpr (PRIME) {
-      update_reference(0.0f);
+      raise_reference(0, lane_max(0), 0.0f);
+      raise_reference(1, lane_max(1), 0.0f);
       return;
     }
-    if constexpr (EXACT) update_reference(THR);
-    static_for<0, (VD < NBT ? VD : NBT)>([&](auto b0) { v_issue(b0); });
     c1[0] = c0 - m_run[0];  // exact (grid argument); +inf while m_run = -inf
     c1[1] = c0 - m_run[1];
-    exp_s(R0{}, R0{});
-    exp_s(R1{}, R0{});
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    pv_s(R0{});
-    exp_s(R0{}, R1{});
-    exp_s(R1{}, R1{});
-    {
-      constexpr int NM = 2 * CB + 2;  // MFMAs of k-step 0: PV + row sums
-      constexpr int NV = 40 / NM;     // 16 fma + 16 exp + 8 cvt of k-step 1 spread over them
-      static_for<0, NM>([&](auto) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
-      });
+    bool dead = false;
+    if constexpr (EXACT) {
+      // Exact path: every tile tests its LANE-partial maxima against the reference - the exponent argument of the largest score
+      // the lane holds, 2 x (8 v_max + 1 v_fma + 1 v_cmp) - and only a wave that finds a row more than 2^THR above its reference
+      // takes the cross-lane step and the rescale.  A wave whose 32 rows all lie more than 2^26 below their references has
+      // nothing to add: every P rounds to +0 in fp16 (P < 2^-25), so its exponentials and PV products are skipped - the
+      // accumulators would not change by a bit (finite V).
+      const float pm0 = lane_max(0), pm1 = lane_max(1);
+      const float a0 = __builtin_fmaf(pm0, sc, c1[0]), a1 = __builtin_fmaf(pm1, sc, c1[1]);
+      if (__any((a0 > THR) || (a1 > THR))) {  // also the first tile (c1 = +inf)
+        raise_reference(0, pm0, THR);
+        raise_reference(1, pm1, THR);
+        c1[0] = c0 - m_run[0];
+        c1[1] = c0 - m_run[1];
+      } else if (LBFA_DEAD_SKIP) {
+        dead = !__any((a0 > kDeadArg) || (a1 > kDeadArg));
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    pv_s(R1{});
-    __builtin_amdgcn_s_setprio(0);
+    if (__builtin_expect(!dead, 1)) {
+      static_for<0, (VD < NBT ? VD : NBT)>([&](auto b0) { v_issue(b0); });
+      exp_s(R0{}, R0{});
+      exp_s(R1{}, R0{});
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      pv_s(R0{});
+      exp_s(R0{}, R1{});
+      exp_s(R1{}, R1{});
+      {
+        constexpr int NM = 2 * CB + 2;  // MFMAs of k-step 0: PV + row sums
+        constexpr int NV = 40 / NM;     // 16 fma + 16 exp + 8 cvt of k-step 1 spread over them
+        static_for<0, NM>([&](auto) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+        });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      pv_s(R1{});
+      __builtin_amdgcn_s_setprio(0);
+    }
   };
 
-  // ---- tile loop (structure of attn_fwd.hip) ---------------------------------------------------------------------
+  // ---- tile loop -----------------------------------------------------------------------------------------------------
+  // One barrier per tile, buffers alternate statically (loop unrolled by two).  Full tiles first, branch-free; then the at
+  // most three tiles that need masking (causal diagonal block = 2 tiles, ragged last tile), which always run the exact path.
+  //
+  // Lazy mode (the first attempt at every Q block): the reference is the exact row max of the first tile, every later
+  // unmasked tile is exponentiated against it as it stands.  A row whose scores outgrow it by more than 2^16 overflows fp16 P:
+  // the infinity reaches its row sum.  The waves look at their row sums after 2, 4, 8, 16, ... tiles and at the end (a vote
+  // through 16 bytes of LDS on the tile's own barrier).  When a wave reports an overflow, the workgroup goes back to tile 0 in
+  // exact mode: the waves that overflowed start over; the others keep what they have, only pass the barriers and fetch
+  // their share of the tiles until the replay reaches the point they had come to, and continue from there in exact mode.  The
+  // waste is at most twice the position of the first overflow, for the waves that overflowed only.
   int n_main = n_tiles;
   if constexpr (CAUSAL) n_main = min(n_tiles, 2 * qt);
   else if ((Sk & 63) != 0) n_main = n_tiles - 1;
@@ -553,67 +583,88 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   using B1 = std::integral_constant<int, 1>;
   using No = std::false_type;
   using Yes = std::true_type;
-  auto step = [&](auto buf_tag, auto nbuf_tag, int i, auto masked_tag, auto exact_tag) __attribute__((always_inline)) {
+  int* vote_flag = reinterpret_cast<int*>(smem + TILES_BYTES);
+  auto wave_overflowed = [&]() __attribute__((always_inline)) {  // every element of the all-ones block is a complete row sum
+    const float chk = l_acc[0][0] + l_acc[1][0];
+    return __any(!(chk < INFINITY)) ? 1 : 0;
+  };
+  int skip_until = 0;  // replay: tiles below this index are already in this wave's accumulators
+  // returns (when `vote`) whether any wave of the workgroup has an overflowed row sum
+  auto step = [&](auto buf_tag, auto nbuf_tag, int i, auto masked_tag, auto exact_tag, bool vote) __attribute__((always_inline)) {
     const int j = tile_of(i);
     if (i != 0 && (j & 63) == (rev ? 63 : 0)) refresh_scale_table(j & ~63);
     load_tile(tile_of(i + 1), nbuf_tag);
     bool skip = false;
     if constexpr (decltype(masked_tag)::value && CAUSAL) skip = j * 64 > row0 + 31;  // all keys above all rows of this wave
+    if constexpr (decltype(exact_tag)::value) skip = skip || i < skip_until;
     if (!skip) compute_tile(buf_tag, j, masked_tag, exact_tag, No{});
     store_tile(nbuf_tag);
+    if (vote) {
+      const int bad = wave_overflowed();
+      if (lane == 0) vote_flag[wave] = bad;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile has landed (this wave's share) when the barrier opens
     __syncthreads();
+    int any_bad = 0;
+    if (vote) {  // the next write to vote_flag is at least one barrier away
+      const i32x4 f = *reinterpret_cast<const i32x4*>(vote_flag);
+      any_bad = __builtin_amdgcn_readfirstlane(f[0] | f[1] | f[2] | f[3]);
+    }
+    return any_bad;
   };
-  auto run_tiles = [&](auto exact_tag) __attribute__((always_inline)) {
+  // tiles [i0, n_tiles), i0 even (tile i0 in buffer 0); lazy mode returns early with the tile count reached when a vote fails
+  auto run_tiles = [&](auto exact_tag, int i0) __attribute__((always_inline)) {
     constexpr bool EX = decltype(exact_tag)::value;
+    int i = i0;
+    for (; i + 1 < n_main; i += 2) {
+      step(B0{}, B1{}, i, No{}, exact_tag, false);
+      const int d = i + 2;
+      const bool vote = !EX && (d & (d - 1)) == 0 && d < n_main;
+      if (step(B1{}, B0{}, i + 1, No{}, exact_tag, vote)) return d;
+    }
+    for (; i < n_tiles; i += 2) {
+      if (i < n_main) step(B0{}, B1{}, i, No{}, exact_tag, false);
+      else step(B0{}, B1{}, i, Yes{}, exact_tag, false);
+      if (i + 1 < n_tiles) {
+        if (i + 1 < n_main) step(B1{}, B0{}, i + 1, No{}, exact_tag, false);
+        else step(B1{}, B0{}, i + 1, Yes{}, exact_tag, false);
+      }
+    }
+    return -1;
+  };
+  auto first_tile_landed = [&]() __attribute__((always_inline)) {
     refresh_scale_table(tile_of(0) & ~63);
     store_tile(B0{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if constexpr (!EX) {
-      if (n_main > 0) compute_tile(B0{}, tile_of(0), No{}, No{}, Yes{});  // reference <- exact row max of the first tile
-    }
-    int i = 0;
-    for (; i + 1 < n_main; i += 2) {
-      step(B0{}, B1{}, i, No{}, exact_tag);
-      step(B1{}, B0{}, i + 1, No{}, exact_tag);
-    }
-    for (; i < n_tiles; i += 2) {
-      if (i < n_main) step(B0{}, B1{}, i, No{}, exact_tag);
-      else step(B0{}, B1{}, i, Yes{}, exact_tag);
-      if (i + 1 < n_tiles) {
-        if (i + 1 < n_main) step(B1{}, B0{}, i + 1, No{}, exact_tag);
-        else step(B1{}, B0{}, i + 1, Yes{}, exact_tag);
-      }
-    }
   };
 
   LBFA_STAMP(2);
-  run_tiles(No{});
+  first_tile_landed();
+  if (n_main > 0) compute_tile(B0{}, tile_of(0), No{}, No{}, Yes{});  // reference <- exact row max of the first tile
+  int replay_end = run_tiles(No{}, 0);
   LBFA_STAMP(3);
-  float l_tot[2];
-  auto row_sum = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) l_tot[rb] = l_acc[rb][0];  // every element of the all-ones block is the complete row sum
-  };
-  row_sum();
-  {
-    // Deferred fp16-overflow vote, one decision per workgroup: an infinite P makes the row sum infinite (or NaN), whatever it
-    // does to the outputs.  The four waves share the K / V tiles and the barriers, so they redo the Q block together.
-    int* flag = reinterpret_cast<int*>(smem + TILES_BYTES);
-    float chk = l_tot[0] + l_tot[1];
-    const int bad = __any(!(chk < INFINITY)) ? 1 : 0;
-    if (lane == 0) flag[wave] = bad;
+  int my_bad = 0;
+  if (replay_end < 0) {  // the lazy pass came to the end: the last vote, on a barrier of its own
+    my_bad = wave_overflowed();
+    if (lane == 0) vote_flag[wave] = my_bad;
     __syncthreads();
-    const int any_bad = flag[0] | flag[1] | flag[2] | flag[3];
-    __syncthreads();
-    if (__builtin_amdgcn_readfirstlane(any_bad)) {
-      reset_state();
-      load_tile(tile_of(0), B0{});
-      run_tiles(Yes{});
-      row_sum();
-    }
+    const i32x4 f = *reinterpret_cast<const i32x4*>(vote_flag);
+    if (__builtin_amdgcn_readfirstlane(f[0] | f[1] | f[2] | f[3])) replay_end = n_tiles;
+  } else {
+    my_bad = wave_overflowed();
   }
+  if (replay_end >= 0) {
+    __syncthreads();  // every wave has read the flags and left the tile buffers
+    if (my_bad) reset_state();
+    skip_until = my_bad ? 0 : replay_end;
+    load_tile(tile_of(0), B0{});
+    first_tile_landed();
+    run_tiles(Yes{}, 0);
+  }
+  float l_tot[2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) l_tot[rb] = l_acc[rb][0];
 
   LBFA_STAMP(4);
   // ---- epilogue: O = O^T / l, LSE ------------------------------------------------------------------------------

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Static check of the SHIPPED gfx950 code object for the XDL-write -> VALU-read hazard behind the 16-pass block-scaled MFMA.
+"""Static checks of the SHIPPED gfx950 code object: (1) the XDL-write -> VALU-read hazard behind the 16-pass block-scaled MFMA
+(below); (2) the hand-counted waits of the inline-asm `ds_read_b64_tr_b16` V^T reads (check_tr_reads); (3) scratch traffic
+inside the loops of the attention kernels (scratch_in_loops).
 
 Background (DESIGN.md 3.1, fp8 PV): `v_mfma_scale_f32_32x32x64_f8f6f4` with e4m3 operands takes 16 passes (64 cycles: twice
 the cycles of the bf16 32x32 form, MI355X_MICROARCH.md, Matrix cores); with fp6 / fp4 operands the same opcode takes 8.  gfx950
@@ -137,6 +139,91 @@ def check_function(ins: list) -> list:
     return res
 
 
+_LGKM_PREFIXES = ("ds_", "s_load", "s_buffer_load", "s_scratch_load", "s_dcache", "s_memtime", "s_memrealtime", "s_sendmsg",
+                  "s_atc_probe", "s_atomic", "s_buffer_atomic", "s_store", "s_buffer_store")
+_lgkm = re.compile(r"lgkmcnt\((\d+)\)")
+
+
+def check_tr_reads(ins: list) -> list:
+    """The V^T fragments are read by inline-asm `ds_read_b64_tr_b16` whose completion the source counts by hand
+    (attn_common.h, lds_wait_keep).  For every such read, on every successor path: no instruction may read or write a destination
+    register before an `s_waitcnt lgkmcnt(n)` that covers the read - n <= the number of LDS operations issued after it (LDS
+    returns in order), or n == 0 once a scalar-memory operation (out of order) has been issued in between.
+    -> [(addr, offending instruction)]"""
+    index = {a: i for i, (a, _, _, _) in enumerate(ins)}
+    bad = []
+    for i, (addr, mn, ops, _) in enumerate(ins):
+        if mn != "ds_read_b64_tr_b16":
+            continue
+        dst = _regs(ops.split(",")[0])
+        seen: dict = {}
+        stack = [(i + 1, 0, False)]
+        hit = None
+        while stack and hit is None:
+            j, younger, smem = stack.pop()
+            while j < len(ins):
+                key = (younger, smem)
+                if key in seen.setdefault(j, set()):
+                    break
+                seen[j].add(key)
+                a2, mn2, ops2, tgt2 = ins[j]
+                if mn2 == "s_waitcnt":
+                    m = _lgkm.search(ops2)
+                    if m is not None:
+                        n = int(m.group(1))
+                        if n == 0 or (not smem and n <= younger):
+                            break  # covered on this path
+                elif _regs(ops2) & dst:
+                    hit = f"{a2:x}: {mn2} {ops2}"
+                    break
+                if mn2 == "s_endpgm" or mn2.startswith("s_setpc") or mn2.startswith("s_swappc"):
+                    hit = f"{a2:x}: {mn2} (read never waited for)"
+                    break
+                if mn2.startswith(_LGKM_PREFIXES):
+                    if mn2.startswith("ds_"):
+                        younger += 1
+                    else:
+                        smem = True
+                    younger = min(younger, 64)
+                if mn2 == "s_branch":
+                    if tgt2 in index:
+                        j = index[tgt2]
+                        continue
+                    break
+                if mn2.startswith("s_cbranch") and tgt2 in index:
+                    stack.append((index[tgt2], younger, smem))
+                j += 1
+        if hit is not None:
+            bad.append((addr, hit))
+    return bad
+
+
+def scratch_in_loops(ins: list) -> int:
+    """number of scratch_* instructions inside loop bodies (address ranges closed by a backward branch) of one function"""
+    spans = [(tgt, a) for (a, mn, _, tgt) in ins if (mn.startswith("s_cbranch") or mn == "s_branch") and tgt is not None and tgt <= a]
+    n = 0
+    for a, mn, _, _ in ins:
+        if mn.startswith("scratch_") and any(lo <= a <= hi for lo, hi in spans):
+            n += 1
+    return n
+
+
+def check_attention_kernels(so_path: str) -> dict:
+    """tr-read waits and in-loop scratch traffic of every attention kernel instance in the library"""
+    fns = parse(disassemble(so_path))
+    rep = {"tr_reads": 0, "tr_violations": [], "scratch_in_loops": {}}
+    for name, ins in fns.items():
+        if "attn_fwd" not in name:
+            continue
+        rep["tr_reads"] += sum(1 for x in ins if x[1] == "ds_read_b64_tr_b16")
+        for addr, what in check_tr_reads(ins):
+            rep["tr_violations"].append((name, hex(addr), what))
+        n = scratch_in_loops(ins)
+        if n:
+            rep["scratch_in_loops"][name] = n
+    return rep
+
+
 def check(so_path: str) -> dict:
     fns = parse(disassemble(so_path))
     report = {"mfma_scale": 0, "min_wait_states": HORIZON, "short": [], "required": NEED_READ}
@@ -160,4 +247,11 @@ if __name__ == "__main__":
         print("closest:", rep["closest"])
     for s in rep["short"][:20]:
         print("SHORT:", s)
-    sys.exit(1 if rep["short"] else 0)
+    rep2 = check_attention_kernels(so)
+    print(f"{rep2['tr_reads']} hand-issued ds_read_b64_tr_b16; destination touched before a covering lgkmcnt wait: {len(rep2['tr_violations'])}")
+    for s in rep2["tr_violations"][:20]:
+        print("EARLY:", s)
+    print(f"attention kernels with scratch traffic inside a loop: {len(rep2['scratch_in_loops'])}")
+    for k, v in sorted(rep2["scratch_in_loops"].items()):
+        print(f"  {v:4d}  {k}")
+    sys.exit(1 if (rep["short"] or rep2["tr_violations"]) else 0)

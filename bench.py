@@ -124,9 +124,14 @@ def make_inputs(torch, dev, B, H, Hkv, S, D, layout, seed, dist_kind="normal", d
     return q, k, v
 
 
-def time_fn(torch, f, iters, warmup=2):
-    for _ in range(warmup):
+def time_fn(torch, f, iters, warmup=2, warm_s=0.1):
+    torch.cuda.synchronize()
+    tw, nw = time.perf_counter(), 0
+    while nw < warmup or (time.perf_counter() - tw) < warm_s:
         f()
+        nw += 1
+        if nw % 4 == 0:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
@@ -144,8 +149,14 @@ def sweep_point(torch, lb, lib, dev, name, spec, iters, refs=True, dist_kind="no
     q, k, v = make_inputs(torch, dev, B, H, Hkv, S, D, layout, 99, dist_kind, dtype)
     f = lambda: fn(q, k, v, tensor_layout=layout, is_causal=causal, **extra)
     flops = 4.0 * B * H * D * S * S / (2 if causal else 1)
-    for _ in range(3):
+    # un-counted launches for >= 150 ms (at least 3): the row before may have left the device idle (host-side baselines, frees)
+    torch.cuda.synchronize()
+    tw, nw = time.perf_counter(), 0
+    while nw < 3 or (time.perf_counter() - tw) < 0.15:
         f()
+        nw += 1
+        if nw % 4 == 0:
+            torch.cuda.synchronize()
     evs = []
     for _ in range(iters):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

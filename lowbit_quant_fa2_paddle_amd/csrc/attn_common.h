@@ -64,29 +64,22 @@ __device__ __forceinline__ float rows4_sum(float x) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 // "Order keys": the scores of the int8 product are the accumulator bits of kMagic + s, which compare like the integers s as
-// signed int32 (-inf = 0xFF800000 sorts below all of them) - integer maxima need no NaN canonicalisation in front; the fp32
-// scores of the un-quantised product compare as floats (v_max*_f32 by hand: the compiler would put a canonicalising v_max in
-// front of an fmaxf on MFMA output).
+// signed int32 (-inf = 0xFF800000 sorts below all of them) - integer maxima need no NaN canonicalisation in front and come as
+// v_max3_i32.  The fp32 scores of the un-quantised product compare as floats: max(a, b) = med3(a, b, +inf), one v_med3_f32
+// without the canonicalising v_max the compiler puts in front of an fmaxf on MFMA output.  (Not inline asm: hipcc pads no
+// MFMA -> VALU wait states for an asm statement's operands - a hand-written v_max3_f32 read the score accumulators early.)
 template <bool AS_INT>
 __device__ __forceinline__ float key_max(float a, float b) {
   if constexpr (AS_INT) {
     const int x = __float_as_int(a), y = __float_as_int(b);
     return __int_as_float(x > y ? x : y);
   } else {
-    float d;
-    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
+    return __builtin_amdgcn_fmed3f(a, b, __builtin_inff());
   }
 }
 template <bool AS_INT>
 __device__ __forceinline__ float key_max3(float a, float b, float c) {
-  if constexpr (AS_INT) {
-    return key_max<true>(key_max<true>(a, b), c);  // selected as v_max3_i32
-  } else {
-    float d;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-  }
+  return key_max<AS_INT>(key_max<AS_INT>(a, b), c);  // int: selected as v_max3_i32
 }
 template <bool AS_INT>
 __device__ __forceinline__ float rows4_key_max(float x) {

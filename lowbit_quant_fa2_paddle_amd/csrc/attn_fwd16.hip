@@ -81,7 +81,11 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   constexpr int CB = D / 16;               // 16-channel blocks of O^T
   constexpr int KBYTES = 64 * RB, VBYTES = 128 * D;
   constexpr int KCH = KBYTES / 4096, VCH = VBYTES / 4096;  // 16-byte chunks per thread
-  constexpr bool DMA_V = (VT != LBFA_BF16);  // bf16 V is converted to fp16 on the way in: registers + ds_write
+  // P and V of the PV product: fp16 x fp16 (the reference's `p.to(float16)` x `v.to(float16)`, attn_qk_int8_per_block.py:59-61,
+  // src/core.py:307-308) for the int8 operators; the un-quantised bf16 kernel keeps both in bf16 (as a bf16 FlashAttention-2 does)
+  constexpr bool PV_BF16 = (QT == LBFA_BF16);
+  static_assert(!PV_BF16 || VT == LBFA_BF16, "un-quantised kernels take Q, K, V of one dtype");
+  constexpr bool DMA_V = PV_BF16 || (VT != LBFA_BF16);  // int8 operators: bf16 V is converted to fp16 on the way in (registers + ds_write)
   constexpr int TILES_BYTES = 2 * (KBYTES + VBYTES);
   __shared__ __attribute__((aligned(16))) char smem[TILES_BYTES + 16];  // ONE LDS object (see attn_fwd.hip)
 
@@ -324,10 +328,16 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   // channel block whose V^T rows are all ones - one more 16x16x32 MFMA per row block and k-step (8 issue cycles for 128
   // additions; 32 v_add_f32 would take 128) - and every accumulator element of that block IS the complete row sum of the lane's
   // query: no cross-lane step at the end either.
-  f16x8 ones8;
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  f16x8 ones8;  // the bit patterns of eight ones in the PV dtype
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ones8[e] = (_Float16)1.0f;
+  for (int e = 0; e < 8; ++e) ones8[e] = __builtin_bit_cast(_Float16, (unsigned short)(PV_BF16 ? 0x3F80 : 0x3C00));
   asm volatile("" : "+v"(ones8));  // opaque: otherwise re-materialised in every tile
+  // one PV MFMA: A = V^T (or the ones), B = P^T, both as raw 16-bit fragments
+  auto pv_mfma = [&](f16x8 a, f16x8 b, f32x4 c) __attribute__((always_inline)) {
+    if constexpr (PV_BF16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  };
   f32x4 acc_o[2][CB];
   f32x4 l_acc[2];
   float m_run[2];
@@ -361,7 +371,13 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   const int gexp = (int)((__float_as_uint(1.25f * kMagic * sc_max) >> 23) & 0xff) - 127 + 1 - 21;  // log2(G)
   const float G = uniform(__builtin_ldexpf(1.0f, gexp)), invG = uniform(__builtin_ldexpf(1.0f, -gexp));
   const float gg = uniform(__builtin_ldexpf(1.0f, gexp - 22)), invg = uniform(__builtin_ldexpf(1.0f, 22 - gexp));
-  auto grid_up = [&](float m) __attribute__((always_inline)) { return __builtin_ceilf(m * invG) * G; };
+  // Wide scores: the grid is one integer step of a score wide at best (G in (7.5, 15] sc_max), and a reference rounded up to it puts
+  // the largest P at 2^-G.  Harmless while a step is a fraction of a binade; inputs whose 8-bit (4-bit) steps are binades apart -
+  // the reference's bench distribution randint(-100, 100) on the 4-bit-range codes: G = 256 - take the bias off the scores with one
+  // exact subtraction each instead (tv - kMagic = s), keep the scales and the reference unrounded, and pay 32 VALU per tile.
+  const bool wide = !QK16 && gexp >= 2;
+  const float bias = wide ? kMagic : 0.f;
+  auto grid_up = [&](float m) __attribute__((always_inline)) { return wide ? m : __builtin_ceilf(m * invG) * G; };
   float sc_tab = 0.f, c0_tab = 0.f;
   auto refresh_scale_table = [&](int j0) __attribute__((always_inline)) {
     if constexpr (!QK16) {
@@ -369,6 +385,10 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
       const float ks_l = j0 == 0 ? ks_first : (jt < nK ? ksc[jt * ksc_blk] : 0.f);
       sc_tab = fmaxf(__builtin_rintf(qsc * ks_l * invg), 1.0f) * gg;  // >= one grid step: a masked key must not meet sc = 0
       c0_tab = -kMagic * sc_tab;
+      if (wide) {
+        sc_tab = fmaxf(qsc * ks_l, 1e-30f);
+        c0_tab = 0.f;
+      }
     }
   };
 
@@ -397,7 +417,6 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
           if constexpr (QT == LBFA_BF16) {
-            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
             const bf16x8 ka = __builtin_bit_cast(bf16x8, kf), qb = __builtin_bit_cast(bf16x8, qf[rb][s]);
             if (s == 0) facc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             else facc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qb, facc[rb], 0, 0, 0);
@@ -442,7 +461,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
     // what has been accumulated against the old one (the rare path: cross-lane maximum, grid rounding, O-wide multiply).
     auto raise_reference = [&](int rb, float pm, float thr) __attribute__((always_inline)) {
       const float tmax = rows4_key_max<!QK16>(pm);
-      const float xmax = __builtin_fmaf(tmax, sc, c0);
+      const float xmax = __builtin_fmaf(QK16 ? tmax : tmax - bias, sc, c0);
       const float m_cand = fmaxf(m_run[rb], QK16 ? xmax : grid_up(xmax));
       if (__any(m_cand > m_run[rb] + thr)) {
         const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_cand);  // m_run = -inf -> 0
@@ -469,7 +488,10 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pf[rb][s][4 * k2 + e] = (_Float16)x[rb][2 * s + k2][e];
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (PV_BF16) pf[rb][s][4 * k2 + e] = __builtin_bit_cast(_Float16, (__bf16)x[rb][2 * s + k2][e]);
+          else pf[rb][s][4 * k2 + e] = (_Float16)x[rb][2 * s + k2][e];
+        }
     };
     // O^T += V^T P^T.  The V^T fragments of a tile are read in NBT = 2 CB / VG batches of VG channel blocks (every fragment
     // serves both row blocks); batch b + VD is requested before the MFMAs of batch b are issued (VD + 1 register sets, counted
@@ -500,7 +522,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
         const f16x4 lo = vb_lo[slot][ci], hi = vb_hi[slot][ci];
         const f16x8 vf = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) acc_o[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[rb][s], acc_o[rb][cb], 0, 0, 0);
+        for (int rb = 0; rb < 2; ++rb) acc_o[rb][cb] = pv_mfma(vf, pf[rb][s], acc_o[rb][cb]);
       });
     };
     auto pv_s = [&](auto s_tag) __attribute__((always_inline)) {
@@ -511,7 +533,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
         v_use(std::integral_constant<int, bb>{});
       });
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) l_acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[rb][s], l_acc[rb], 0, 0, 0);
+      for (int rb = 0; rb < 2; ++rb) l_acc[rb] = pv_mfma(ones8, pf[rb][s], l_acc[rb]);
     };
     using R0 = std::integral_constant<int, 0>;
     using R1 = std::integral_constant<int, 1>;
@@ -532,7 +554,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
       // nothing to add: every P rounds to +0 in fp16 (P < 2^-25), so its exponentials and PV products are skipped - the
       // accumulators would not change by a bit (finite V).
       const float pm0 = lane_max(0), pm1 = lane_max(1);
-      const float a0 = __builtin_fmaf(pm0, sc, c1[0]), a1 = __builtin_fmaf(pm1, sc, c1[1]);
+      const float a0 = __builtin_fmaf(QK16 ? pm0 : pm0 - bias, sc, c1[0]), a1 = __builtin_fmaf(QK16 ? pm1 : pm1 - bias, sc, c1[1]);
       if (__any((a0 > THR) || (a1 > THR))) {  // also the first tile (c1 = +inf)
         raise_reference(0, pm0, THR);
         raise_reference(1, pm1, THR);
@@ -543,6 +565,16 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
       }
     }
     if (__builtin_expect(!dead, 1)) {
+      if constexpr (!QK16) {
+        if (wide) {  // wave-uniform: scores as the integers themselves
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) x[rb][kb][e] -= kMagic;
+        }
+      }
       static_for<0, (VD < NBT ? VD : NBT)>([&](auto b0) { v_issue(b0); });
       exp_s(R0{}, R0{});
       exp_s(R1{}, R0{});

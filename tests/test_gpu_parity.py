@@ -49,6 +49,18 @@ def _o_close(o, ref, dtype, atol=2e-3, rtol=2e-3):
     assert not bad.any(), f"max err {err.max():.3e} at {np.argwhere(bad)[:3].tolist()} ({bad.sum()} elements)"
 
 
+def _fp8_close(o, ref):
+    """fp8-PV against the oracle's restatement (parity unpinned).  P is rounded to e4m3 (3 mantissa bits): a 1-ulp
+    difference of exp2 at a rounding boundary flips a code (6 % of that P), which shows in rows with few keys (the first rows of
+    a causal block move by up to ~6 % |v|).  Loose element bound, tight bounds on the fraction of such elements and the mean
+    square."""
+    err = np.abs(o - ref)
+    assert (err <= 0.1 + 6e-2 * np.abs(ref)).all(), f"max err {err.max():.3e}"
+    loose = err > 1e-2 + 2e-2 * np.abs(ref)
+    assert loose.mean() <= 5e-3, f"{loose.sum()} of {loose.size} elements beyond 1e-2 + 2e-2 |ref|"
+    assert float(np.mean((o - ref) ** 2)) <= 1e-5
+
+
 # ------------------------------------------------------------------------------------------------------
 # quantiser
 # ------------------------------------------------------------------------------------------------------
@@ -213,7 +225,7 @@ def test_operator_int8_fp8_vs_oracle(oracle, dev, B, H, Hkv, S, D, layout, causa
     o, lse = lb.lowbit_fa_qk_int8_pv_fp8_cuda(tq, tk, tv, tensor_layout=layout, is_causal=causal, return_lse=True)
     o_ref, lse_ref = oracle.lowbit_fa_forward(q, k, v, dtype=dtype, tensor_layout=layout, is_causal=causal,
                                               return_lse=True, pv="fp8", amax_floor=1e-7)
-    _o_close(_np(o), o_ref, dtype, atol=1e-2, rtol=2e-2)
+    _fp8_close(_np(o), o_ref)
     assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 2e-3 + 2.0 ** -9 * np.abs(lse_ref).max()
     ref = oracle.sdpa_naive(_canon(q, layout).astype(np.float64), _canon(k, layout).astype(np.float64),
                             _canon(v, layout).astype(np.float64), is_causal=causal)
@@ -231,16 +243,9 @@ def test_v_fp8_quant_exact(oracle, dev):
     assert vm is None
     ref8, ref_s = oracle.per_channel_fp8(v)
     assert np.array_equal(vs.cpu().numpy().view(np.uint32), ref_s.view(np.uint32))
-    raw = v8.buf.cpu().numpy()
-    ntile = (S + 63) // 64
-    tiles = raw[: B * H * ntile * D * 64].reshape(B, H, ntile, D, 64)
+    from fp8_layout import decode_v_fp8
     codes = oracle.e4m3fn_encode(ref8)  # [B,H,S,D]
-    got = np.zeros((B, H, ntile * 64, D), np.uint8)
-    for key in range(64):  # device layout (include/lowbit_fa.h: "a device detail"): MFMA k order + 16-byte chunk swizzle
-        kb2, w = key >> 5, key & 31
-        pos = 32 * ((w >> 2) & 1) + 16 * kb2 + 4 * (w >> 3) + (w & 3)
-        for d in range(D):
-            got[:, :, key::64, d][:, :, :ntile] = tiles[:, :, :, d, (((pos >> 4) ^ ((d >> 2) & 3)) << 4) | (pos & 15)]
+    got = decode_v_fp8(v8.buf.cpu().numpy(), B, H, S, D)  # device layout: MFMA k order + 16-byte chunk swizzle
     assert np.array_equal(got[:, :, :S], codes)
     assert np.all(got[:, :, S:] == 0)
 

@@ -40,6 +40,18 @@ def _o_close(o, ref, atol=2e-3, rtol=2e-3):
     assert not bad.any(), f"max err {err.max():.3e} at {np.argwhere(bad)[:3].tolist()} ({bad.sum()} elements)"
 
 
+def _fp8_close(o, ref):
+    """fp8-PV against the oracle's restatement (parity unpinned).  P is rounded to e4m3 (3 mantissa bits): a 1-ulp
+    difference of exp2 at a rounding boundary flips a code (6 % of that P), which shows in rows with few keys (the first rows of
+    a causal block move by up to ~6 % |v|).  Loose element bound, tight bounds on the fraction of such elements and the mean
+    square."""
+    err = np.abs(o - ref)
+    assert (err <= 0.1 + 6e-2 * np.abs(ref)).all(), f"max err {err.max():.3e}"
+    loose = err > 1e-2 + 2e-2 * np.abs(ref)
+    assert loose.mean() <= 5e-3, f"{loose.sum()} of {loose.size} elements beyond 1e-2 + 2e-2 |ref|"
+    assert float(np.mean((o - ref) ** 2)) <= 1e-5
+
+
 @pytest.mark.parametrize("D", [64, 128])
 @pytest.mark.parametrize("S,causal", [(1024, False), (1000, False), (1024, True)])
 @pytest.mark.parametrize("smooth_k", [False, True])
@@ -94,9 +106,12 @@ def test_zero_k_block_in_a_masked_tile(oracle, dev, variant, S, causal, zero_lo,
     else:
         o = lb.lowbit_fa_qk_int8_pv_fp8_cuda(tq, tk, tv, is_causal=causal, smooth_k=False)
         ref = oracle.lowbit_fa_forward(q, k, v, is_causal=causal, smooth_k=False, pv="fp8", amax_floor=1e-7, tail="neg_inf")
-        tol = dict(atol=1e-2, rtol=2e-2)  # fp8-PV: parity unpinned, loose against the oracle's restatement
+        tol = None  # fp8-PV: parity unpinned, loose against the oracle's restatement (_fp8_close)
     assert torch.isfinite(o).all()
-    _o_close(_np(o), ref, **tol)
+    if tol is None:
+        _fp8_close(_np(o), ref)
+    else:
+        _o_close(_np(o), ref, **tol)
 
 
 def test_varlen_understated_max_seqlen_is_a_cut_not_an_overrun(oracle, dev):
@@ -141,14 +156,8 @@ def test_p_to_e4m3_conversion_bit_exact(oracle, dev):
     tv = torch.from_numpy(v).to(torch.float16).to(dev)
     v8, v_scale, _ = quant.per_channel_fp8(tv, tensor_layout="HND")
     assert float(v_scale[0, 0, 0]) == 1.0
-    raw = v8.buf.cpu().numpy()
-    ntile = S // 64
-    tiles = raw[: ntile * D * 64].reshape(ntile, D, 64)
-    got = np.zeros(S, np.uint8)
-    for key in range(64):  # device layout of lbfa_quant_v_fp8: MFMA k order + 16-byte chunk swizzle (channel d = 0)
-        kb2, w = key >> 5, key & 31
-        pos = 32 * ((w >> 2) & 1) + 16 * kb2 + 4 * (w >> 3) + (w & 3)
-        got[key::64] = tiles[:, 0, (((pos >> 4) ^ 0) << 4) | (pos & 15)]
+    from fp8_layout import decode_v_fp8
+    got = decode_v_fp8(v8.buf.cpu().numpy(), 1, 1, S, D)[0, 0, :, 0]  # channel 0 in key order
     want = oracle.e4m3fn_encode(oracle.e4m3fn_round(v[0, 0, :, 0]))
     got[got == 0x80] = 0   # -0 and +0 are the same number: the device keeps the sign of a negative input that rounds to zero,
     want[want == 0x80] = 0  # numpy's sign() drops it
@@ -176,6 +185,8 @@ def test_reversed_rounds_of_q_blocks_vs_oracle(oracle, dev, D, S, first_rev_row,
     rows = slice(lo, min(lo + 640, S))  # one forward block + the first reversed ones (whole 128-row quantisation blocks)
     ref, lse_ref = oracle.lowbit_fa_forward(q[:, :, rows], k, v, return_lse=True, amax_floor=1e-7,
                                             pv="fp8" if variant == "fp8" else "fp16")
-    tol = dict(atol=2e-3, rtol=2e-3) if variant == "fp16" else dict(atol=1e-2, rtol=2e-2)
-    _o_close(_np(o)[:, :, rows], ref, **tol)
+    if variant == "fp16":
+        _o_close(_np(o)[:, :, rows], ref)
+    else:
+        _fp8_close(_np(o)[:, :, rows], ref)
     assert np.abs(lse.cpu().numpy()[:, :, rows] - lse_ref).max() <= (1e-3 if variant == "fp16" else 2e-3) + 2.0 ** -9 * np.abs(lse_ref).max()

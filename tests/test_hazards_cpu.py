@@ -19,4 +19,4 @@ def test_scaled_mfma_results_are_not_read_early():
     rep = chk.check(so)
     assert rep["mfma_scale"] >= 32, rep  # the fp8-PV instances are in the binary
     assert not rep["short"], rep["short"][:5]
-    assert rep["min_wait_states"] >= chk.NEED_READ
+    assert rep["min_wait_states"] >= rep["required"]

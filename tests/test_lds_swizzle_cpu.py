@@ -75,3 +75,4 @@ def test_v_image_is_a_permutation_of_the_tile(d):
     for row in range(64):
         src = [(((ch >> 1) ^ vx16(d, row)) << 1) | (ch & 1) for ch in range(cpr)]
         assert sorted(src) == list(range(cpr))
+

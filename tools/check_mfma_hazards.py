@@ -31,8 +31,13 @@ import tempfile
 LLVM = "/opt/rocm/lib/llvm/bin"
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
-NEED_READ = 20   # 16 passes + 3 + 1
+NEED_READ = 20   # 32x32x64 with e4m3 operands: 16 passes + 3 + 1
+NEED_READ_16 = 12  # 16x16x128 with e4m3 operands: 8 passes + 3 + 1  (not in the shipped library: round 3's 128-key-tile experiment)
 HORIZON = 32     # stop following a path after this many wait states
+
+
+def need_read(mnemonic: str) -> int:
+    return NEED_READ_16 if "16x16x128" in mnemonic else NEED_READ
 
 _reg = re.compile(r"\b([va])(?:(\d+)|\[(\d+):(\d+)\])")
 _fn = re.compile(r"^([0-9a-f]+) <([^>]+)>:$")
@@ -135,7 +140,7 @@ def check_function(ins: list) -> list:
                 if mn2.startswith("s_cbranch") and tgt2 in index:
                     stack.append((index[tgt2], w))
                 j += 1
-        res.append((addr, best, best_ins))
+        res.append((addr, best, best_ins, need_read(mn)))
     return res
 
 
@@ -226,13 +231,14 @@ def check_attention_kernels(so_path: str) -> dict:
 
 def check(so_path: str) -> dict:
     fns = parse(disassemble(so_path))
-    report = {"mfma_scale": 0, "min_wait_states": HORIZON, "short": [], "required": NEED_READ}
+    report = {"mfma_scale": 0, "min_wait_states": HORIZON, "short": [], "required": 0}
     for name, ins in fns.items():
-        for addr, w, what in check_function(ins):
+        for addr, w, what, need in check_function(ins):
             report["mfma_scale"] += 1
+            report["required"] = max(report["required"], need)
             if w < report["min_wait_states"]:
                 report["min_wait_states"], report["closest"] = w, f"{name} @{addr:x} -> {what}"
-            if w < NEED_READ:
+            if w < need:
                 report["short"].append((name, hex(addr), w, what))
     return report
 
@@ -242,7 +248,7 @@ if __name__ == "__main__":
                                                             "lowbit_quant_fa2_paddle_amd", "liblowbit_fa_hip.so")
     rep = check(so)
     print(f"{rep['mfma_scale']} block-scaled MFMAs; fewest wait states before a dependent non-MFMA access: {rep['min_wait_states']}"
-          f"{'+' if rep['min_wait_states'] >= HORIZON else ''} (required {NEED_READ})")
+          f"{'+' if rep['min_wait_states'] >= HORIZON else ''} (required {rep['required']})")
     if "closest" in rep and rep["min_wait_states"] < HORIZON:
         print("closest:", rep["closest"])
     for s in rep["short"][:20]:

@@ -113,9 +113,9 @@ int lbfa_quant_v_fp8(const void* v, int dtype, uint8_t* v_fp8, float* v_scale, i
  * (src/triton/quantization/attn_qk_int4_per_block{,_causal}.py) and, for v_dtype = LBFA_E4M3,
  * `qk_int8_sv_f8_accum_f32_fuse_v_scale_attn*` (csrc/qattn/qk_int_sv_f8_cuda.cu:46-692).
  *   q [B,Hq,Sq,D], k [B,Hkv,Sk,D] : int8 codes (any range within int8: 127 or 7)
- *   v : LBFA_F16 / LBFA_BF16 [B,Hkv,Sk,D] with strides_v (bf16 is converted to fp16 on the way into
- *       LDS, replacing the `v.to(float16)` pass of src/core.py:307-308), or LBFA_E4M3 in the layout of
- *       lbfa_quant_v_fp8 (strides_v ignored) together with v_scale [B,Hkv,D].
+ *   v : LBFA_F16 [B,Hkv,Sk,D] with strides_v - as the reference's kernel, which is only ever handed `v.to(float16)`
+ *       (src/core.py:307-308); a bf16 V is cast with lbfa_cast_bf16_to_f16 first (the one-call entry points do that
+ *       themselves) - or LBFA_E4M3 in the layout of lbfa_quant_v_fp8 (strides_v ignored) together with v_scale [B,Hkv,D].
  *   o : [B,Hq,Sq,D] fp16 or bf16 (o_dtype), strides_o.
  *   lse : NULL, or [B,Hq,Sq] contiguous fp32 receiving log2(l) + m (base-2 domain, exactly what the
  *         reference kernel stores, :164-167; the host converts it, src/core.py:344-350).
@@ -125,6 +125,8 @@ int lbfa_quant_v_fp8(const void* v, int dtype, uint8_t* v_fp8, float* v_scale, i
  *   Triton kernel lets them into the softmax as zeros, a defect that only shows when Sk % 64 != 0).
  *   D in {64, 128}; Hq % Hkv == 0.
  */
+int lbfa_cast_bf16_to_f16(const void* src, void* dst, int B, int H, int S, int D, const int64_t strides_src[3],
+                          const int64_t strides_dst[3], void* stream); /* src/core.py:307-308 `v.to(float16)`; D % 8 == 0 */
 int lbfa_attn_fwd(const int8_t* q, const int8_t* k, const void* v, int v_dtype, void* o, int o_dtype, float* lse,
                   const float* q_scale, const float* k_scale, const float* v_scale,
                   int B, int Hq, int Hkv, int Sq, int Sk, int D,
@@ -148,8 +150,9 @@ int lbfa_profile_next_attn(void* start_event, void* stop_event);
  *   q, k, v : fp16/bf16 (dtype), strides in elements {batch, head, seq}; o same dtype, strides_o.
  *   lse     : NULL, or [B,Hq,Sq] fp32 receiving the NATURAL-log LSE incl. the smooth-K correction
  *             (lse2 / 1.44269504 + (q . km) * sm_scale, src/core.py:344-350).
- *   workspace: >= lbfa_forward_workspace_bytes(...) bytes, 16-byte aligned, caller-owned scratch (int8 codes,
- *             scales, km, partial sums, fp8 V); contents are undefined afterwards.
+ *   workspace: >= lbfa_forward_workspace_bytes_dt(..., dtype, ...) bytes, 16-byte aligned, caller-owned scratch (int8 codes,
+ *             scales, km, partial sums, fp8 V, the fp16 copy of a bf16 V); contents are undefined
+ *             afterwards.  lbfa_forward_workspace_bytes(...) (no dtype) returns the size that is enough for either dtype.
  *   sm_scale: softmax scale (1/sqrt(original head_dim) by default on the host side), a double as in the reference's
  *             Python: the Q quantiser multiplies by fp32(sm_scale * 1.44269504) formed in double
  *             (src/triton/quant_per_block.py:226) - with 4-bit-range codes a 1-ulp difference there flips codes;
@@ -160,6 +163,8 @@ int lbfa_profile_next_attn(void* start_event, void* stop_event);
  *             (lbfa_forward_varlen likewise; the modular entry points take D in {64, 128} only.)
  */
 size_t lbfa_forward_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int pv_fp8, int smooth_k, int return_lse);
+size_t lbfa_forward_workspace_bytes_dt(int B, int Hq, int Hkv, int Sq, int Sk, int D, int dtype, int pv_fp8, int smooth_k,
+                                       int return_lse);
 int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o, float* lse, void* workspace,
                  size_t workspace_bytes, int B, int Hq, int Hkv, int Sq, int Sk, int D,
                  const int64_t strides_q[3], const int64_t strides_k[3], const int64_t strides_v[3],
@@ -213,6 +218,8 @@ int lbfa_attn_fwd_varlen(const int8_t* q, const int8_t* k, const void* v, int v_
                          const int64_t strides_o[2], int is_causal, void* stream);
 size_t lbfa_forward_varlen_workspace_bytes(int B, int Hq, int Hkv, int total_q, int total_k, int max_seqlen_q,
                                            int max_seqlen_k, int D);
+size_t lbfa_forward_varlen_workspace_bytes_dt(int B, int Hq, int Hkv, int total_q, int total_k, int max_seqlen_q,
+                                              int max_seqlen_k, int D, int dtype);
 int lbfa_forward_varlen(const void* q, const void* k, const void* v, int dtype, void* o,
                         const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, void* workspace, size_t workspace_bytes,
                         int B, int Hq, int Hkv, int total_q, int total_k, int max_seqlen_q, int max_seqlen_k, int D,

@@ -12,8 +12,8 @@ from .quant_per_block import _bhs
 
 def forward(q, k, v, q_scale, k_scale, tensor_layout="HND", output_dtype=None, return_lse=False,
             is_causal=False, v_scale=None):
-    """q, k: int8 codes; v: fp16 / bf16 tensor in `tensor_layout`, or an `Fp8V` (+ v_scale) for the fp8-PV
-    kernel.  Returns (o, lse): o like q in `output_dtype` (default fp16), lse [B,Hq,Sq] fp32 in the
+    """q, k: int8 codes; v: fp16 tensor in `tensor_layout` (a bf16 one is cast first, the `v.to(float16)` of
+    src/core.py:307-308, by the library's own kernel), or an `Fp8V` (+ v_scale) for the fp8-PV kernel.  Returns (o, lse): o like q in `output_dtype` (default fp16), lse [B,Hq,Sq] fp32 in the
     kernel's base-2 domain, or an empty tensor when not requested (attn_qk_int8_per_block.py:201-204)."""
     ops = ops_for(q)
     lib = _lib.load()
@@ -41,6 +41,13 @@ def forward(q, k, v, q_scale, k_scale, tensor_layout="HND", output_dtype=None, r
         if v_code is None:
             raise ValueError("v must be float16 or bfloat16 (or the result of per_channel_fp8)")
         (_, _, _), v3s = _bhs(ops.shape(v), ops.strides(v), tensor_layout)
+        if v_code == _lib.LBFA_BF16:
+            v16 = ops.empty(ops.shape(v), ops.float16, v)
+            (_, _, _), d3s = _bhs(ops.shape(v16), ops.strides(v16), tensor_layout)
+            with ops.device_guard(q):
+                _lib.check(lib.lbfa_cast_bf16_to_f16(ops.ptr(v), ops.ptr(v16), B, Hkv, Sk, D, _lib.strides3(v3s),
+                                                     _lib.strides3(d3s), ops.stream(q)), lib)
+            v, v3s, v_code = v16, d3s, _lib.LBFA_F16
         v_ptr, v3 = ops.ptr(v), _lib.strides3(v3s)
     lse = ops.empty((B, Hq, Sq), ops.float32, q) if return_lse else ops.empty((0,), ops.float32, q)
     with ops.device_guard(q):

@@ -92,7 +92,7 @@ def _low_bit_attention(q, k, v, *, tensor_layout, is_causal, sm_scale, smooth_k,
     (_, _, _), o3 = _qpb._bhs(qshape, ops.strides(o), tensor_layout)
     lse = ops.empty((B, Hq, Sq), ops.float32, q) if return_lse else None
     fp8 = 1 if pv == "fp8" else 0
-    ws_bytes = lib.lbfa_forward_workspace_bytes(B, Hq, Hkv, Sq, Sk, D, fp8, 1 if smooth_k else 0, 1 if return_lse else 0)
+    ws_bytes = lib.lbfa_forward_workspace_bytes_dt(B, Hq, Hkv, Sq, Sk, D, ops.dtype_code(q), fp8, 1 if smooth_k else 0, 1 if return_lse else 0)
     ws = ops.empty((ws_bytes,), ops.uint8, q)
     with ops.device_guard(q):
         _lib.check(lib.lbfa_forward(ops.ptr(q), ops.ptr(k), ops.ptr(v), ops.dtype_code(q), ops.ptr(o),
@@ -204,7 +204,7 @@ def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_
     B = ops.shape(cu_q)[0] - 1
     o = ops.empty((total_q, Hq, D), dtype, q)
     hs = lambda t: _lib.strides2((ops.strides(t)[1], ops.strides(t)[0]))  # {head, token}
-    ws_bytes = lib.lbfa_forward_varlen_workspace_bytes(B, Hq, Hkv, total_q, total_k, int(max_seqlen_q), int(max_seqlen_k), D)
+    ws_bytes = lib.lbfa_forward_varlen_workspace_bytes_dt(B, Hq, Hkv, total_q, total_k, int(max_seqlen_q), int(max_seqlen_k), D, ops.dtype_code(q))
     ws = ops.empty((max(ws_bytes, 16),), ops.uint8, q)
     with ops.device_guard(q):
         _lib.check(lib.lbfa_forward_varlen(ops.ptr(q), ops.ptr(k), ops.ptr(v), ops.dtype_code(q), ops.ptr(o),

@@ -491,8 +491,8 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
 // ---- launchers: every fp16-P variant runs in attn_fwd16.hip, fp8 PV here ------------------------------------------
 hipError_t launch16_attn_fwd_d64(const AttnParams& p, int v_dtype, int o_dtype, int causal, hipStream_t stream);
 hipError_t launch16_attn_fwd_d128(const AttnParams& p, int v_dtype, int o_dtype, int causal, hipStream_t stream);
-hipError_t launch16_attn_fwd_qq_d64(const AttnParams& p, int dtype, int causal, hipStream_t stream);
-hipError_t launch16_attn_fwd_qq_d128(const AttnParams& p, int dtype, int causal, hipStream_t stream);
+hipError_t launch16_attn_fwd_qq_d64(const AttnParams& p, int dtype, int v_dtype, int causal, hipStream_t stream);
+hipError_t launch16_attn_fwd_qq_d128(const AttnParams& p, int dtype, int v_dtype, int causal, hipStream_t stream);
 hipError_t launch16_attn_fwd_f16_d64(const AttnParams& p, int dtype, int causal, hipStream_t stream);
 hipError_t launch16_attn_fwd_f16_d128(const AttnParams& p, int dtype, int causal, hipStream_t stream);
 
@@ -502,7 +502,7 @@ hipError_t launch16_attn_fwd_f16_d128(const AttnParams& p, int dtype, int causal
     else hipLaunchKernelGGL((attn_fwd_kernel<DD, OT, false, QQ>), grid, block, 0, stream, p);          \
   } while (0)
 
-// int8 Q / K codes; V fp16 / bf16 / e4m3 ([D][64]-per-tile image of lbfa_quant_v_fp8)
+// int8 Q / K codes; V fp16 / e4m3 ([D][64]-per-tile image of lbfa_quant_v_fp8)
 hipError_t launch_attn_fwd(const AttnParams& p, int D, int v_dtype, int o_dtype, int causal, hipStream_t stream) {
   if (v_dtype != LBFA_E4M3)
     return D == 64 ? launch16_attn_fwd_d64(p, v_dtype, o_dtype, causal, stream) : launch16_attn_fwd_d128(p, v_dtype, o_dtype, causal, stream);
@@ -512,9 +512,10 @@ hipError_t launch_attn_fwd(const AttnParams& p, int D, int v_dtype, int o_dtype,
   return hipGetLastError();
 }
 
-// int8 K codes, Q quantised inside the kernel from its fp16 / bf16 source (dtype = Q's = O's); V of the same dtype or e4m3
-hipError_t launch_attn_fwd_qq(const AttnParams& p, int D, int dtype, int v_fp8, int causal, hipStream_t stream) {
-  if (!v_fp8) return D == 64 ? launch16_attn_fwd_qq_d64(p, dtype, causal, stream) : launch16_attn_fwd_qq_d128(p, dtype, causal, stream);
+// int8 K codes, Q quantised inside the kernel from its fp16 / bf16 source (dtype = Q's = O's); V fp16 or e4m3
+hipError_t launch_attn_fwd_qq(const AttnParams& p, int D, int dtype, int v_dtype, int causal, hipStream_t stream) {
+  if (v_dtype != LBFA_E4M3)
+    return D == 64 ? launch16_attn_fwd_qq_d64(p, dtype, v_dtype, causal, stream) : launch16_attn_fwd_qq_d128(p, dtype, v_dtype, causal, stream);
   dim3 grid((unsigned)p.B * p.Hq * p.nQ), block(256);
   if (D == 64) { if (dtype == LBFA_F16) LBFA_LAUNCH_FP8(64, LBFA_F16, true); else LBFA_LAUNCH_FP8(64, LBFA_BF16, true); }
   else { if (dtype == LBFA_F16) LBFA_LAUNCH_FP8(128, LBFA_F16, true); else LBFA_LAUNCH_FP8(128, LBFA_BF16, true); }

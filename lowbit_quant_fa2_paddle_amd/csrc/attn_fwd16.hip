@@ -20,11 +20,14 @@
 //                 C: lane holds, for its query, channels 16 cb + 4 g + {0..3}
 //   A query row's scores live in four lanes (g = 0..3): a row max needs two cross-group steps, which only the exact path (masked
 //   tiles, re-run) takes; the row sums come out of one more PV block against an all-ones V^T (every lane gets the complete sum).
-// Lazy softmax reference with a DEFERRED overflow check: the first tile of a Q block sets the reference m (exact row max, no PV),
-// every later unmasked tile is exponentiated against m AS IT STANDS - any reference within 2^15 of the row max is as good as the
-// max (P is floating point, fp32 accumulate) - and nothing inside the tile loop looks at the result.  A row whose scores outgrow
-// m by more than 2^16 overflows fp16 P: the infinity reaches its row sum, the workgroup votes ONCE after the loop and, if any row
-// is not finite, redoes the Q block with the exact row max in every tile (run_tiles(Yes), the code path of the masked tiles).
+// Lazy softmax reference with EARLY overflow votes: the first tile of a Q block takes the exact path and its row maxima become
+// the reference m; every later unmasked tile is exponentiated against m AS IT STANDS - any reference within 2^15 of the row max
+// is as good as the max (P is floating point, fp32 accumulate) - one fma + one exp per score and no row max.  A row whose scores
+// outgrow m by more than 2^16 overflows fp16 P: the infinity reaches its row sum.  The waves look at their row sums after 2, 4,
+// 8, ... tiles and at the end; when one reports an overflow the workgroup replays from tile 0 in exact mode (lane-partial
+// integer maxima every tile, cross-lane step and rescale only where a row outgrew its reference by 2^8): the waves that
+// overflowed start over, the others keep their accumulators and only pass the barriers until the replay reaches the point they
+// had come to ("tile loop" below).
 // LDS images (checked conflict-free by enumeration of the hardware's lane groups):
 //   K tile [64][RB bytes]: 16-byte chunk c of row r at c ^ kx16(r), kx16 = (r >> 1) & 3 | r & 7 | r & 15 for RB = 64 | 128 | 256
 //   V tile [64][2 D bytes]: 32-byte block c of row r at c ^ vx16(r), vx16 = (r >> 1) & 3 (D = 64) | r & 7 (D = 128)
@@ -34,10 +37,6 @@
 namespace lbfa {
 
 constexpr float kLazyThr = 8.0f;  // exact paths move the softmax reference only when a row max outgrows it by more than 2^8
-#ifndef LBFA_DEAD_SKIP
-#define LBFA_DEAD_SKIP 0
-#endif
-constexpr float kDeadArg = -26.0f;  // exp2 arguments below this give P < 2^-25, which rounds to +0 in fp16
 constexpr bool kPingPong = true;  // every other round of Q blocks walks the key tiles backwards (L2 reuse, see attn_fwd.hip)
 // V^T fragments are read in batches of kVBatch channel blocks (4 registers each), kVAhead batches ahead of the MFMAs that use
 // them (kVAhead + 1 register sets).  Measured (S16K / D128 / C3): one block ahead at 1 / 2 blocks per batch +1 / +3..5 / +2 % over
@@ -82,10 +81,10 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   constexpr int KBYTES = 64 * RB, VBYTES = 128 * D;
   constexpr int KCH = KBYTES / 4096, VCH = VBYTES / 4096;  // 16-byte chunks per thread
   // P and V of the PV product: fp16 x fp16 (the reference's `p.to(float16)` x `v.to(float16)`, attn_qk_int8_per_block.py:59-61,
-  // src/core.py:307-308) for the int8 operators; the un-quantised bf16 kernel keeps both in bf16 (as a bf16 FlashAttention-2 does)
+  // src/core.py:307-308: a bf16 V reaches the int8 operators already cast, lbfa_cast_bf16_to_f16) for the int8 operators; the
+  // un-quantised bf16 kernel keeps both in bf16 (as a bf16 FlashAttention-2 does).  V tiles always arrive by LDS-DMA.
   constexpr bool PV_BF16 = (QT == LBFA_BF16);
-  static_assert(!PV_BF16 || VT == LBFA_BF16, "un-quantised kernels take Q, K, V of one dtype");
-  constexpr bool DMA_V = PV_BF16 || (VT != LBFA_BF16);  // int8 operators: bf16 V is converted to fp16 on the way in (registers + ds_write)
+  static_assert(VT == (PV_BF16 ? LBFA_BF16 : LBFA_F16), "int8 operators and the fp16 kernel take fp16 V, the bf16 kernel bf16 V");
   constexpr int TILES_BYTES = 2 * (KBYTES + VBYTES);
   __shared__ __attribute__((aligned(16))) char smem[TILES_BYTES + 16];  // ONE LDS object (see attn_fwd.hip)
 
@@ -156,7 +155,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   // ---- loop-invariant per-thread offsets of the tile fetch (one 16-byte chunk per thread and pass of 256 threads) ----
   constexpr int KCPR = RB / 16, KROWS = 256 / KCPR;
   constexpr int VCPR = D / 8, VROWS = 256 / VCPR;
-  unsigned k_goff, v_goff, v_loff;
+  unsigned k_goff, v_goff;
   {
     const int row = t / KCPR, ch = t % KCPR;
     const int gch = ch ^ kx16<RB>(row);  // LDS-DMA writes linearly: the slot (row, ch) holds global chunk ch ^ kx16(row)
@@ -164,15 +163,12 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   }
   {
     const int row = t / VCPR, ch = t % VCPR;
-    const int sw = (((ch >> 1) ^ vx16<D>(row)) << 1) | (ch & 1);
-    const int gch = DMA_V ? sw : ch;
+    const int gch = (((ch >> 1) ^ vx16<D>(row)) << 1) | (ch & 1);  // LDS-DMA writes linearly: the swizzle moves to the source
     v_goff = gch * 8 < p.d_valid ? 2 * ((unsigned)row * (unsigned)p.vs) + gch * 16 : 0x80000000u;
-    v_loff = 2 * KBYTES + row * (2 * D) + sw * 16;
   }
   const unsigned k_gstep = ESZ * KROWS * (unsigned)p.ks;
   const unsigned v_gstep = 2u * VROWS * (unsigned)p.vs;
   static_assert(KROWS * RB == 4096 && VROWS * 2 * D == 4096, "one pass of 256 threads x 16 bytes");
-  u32x4 vreg[DMA_V ? 1 : VCH];
   const int k_bytes32 = (int)k_bytes, v_bytes32 = (int)v_bytes, k_stride32 = (int)k_tile_stride, v_stride32 = (int)v_tile_stride;
   typedef __attribute__((address_space(3))) void* lds_void_ptr;
   auto load_tile = [&](int j, auto buf_tag) __attribute__((always_inline)) {
@@ -186,25 +182,10 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
 #pragma unroll
     for (int c = 0; c < KCH; ++c)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rs, (lds_void_ptr)(kdst + c * 4096), 16, (int)k_goff, (int)(c * k_gstep), 0, 0);
-    if constexpr (DMA_V) {
-      char* vdst = smem + 2 * KBYTES + BUF * VBYTES + wave * 1024;
+    char* vdst = smem + 2 * KBYTES + BUF * VBYTES + wave * 1024;
 #pragma unroll
-      for (int c = 0; c < VCH; ++c)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rs, (lds_void_ptr)(vdst + c * 4096), 16, (int)v_goff, (int)(c * v_gstep), 0, 0);
-    } else {
-#pragma unroll
-      for (int c = 0; c < VCH; ++c) vreg[c] = buf_load16(v_rs, v_goff, c * v_gstep);
-    }
-  };
-  auto store_tile = [&](auto buf_tag) __attribute__((always_inline)) {
-    constexpr int BUF = decltype(buf_tag)::value;
-    if constexpr (!DMA_V) {
-#pragma unroll
-      for (int c = 0; c < VCH; ++c) {
-        u32x4 val = bf16x8_to_f16x8(vreg[c]);  // bf16 -> fp16 on the way in (src/core.py:307-308 `v.to(float16)`)
-        *reinterpret_cast<u32x4*>(smem + v_loff + c * 4096 + BUF * VBYTES) = val;
-      }
-    }
+    for (int c = 0; c < VCH; ++c)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rs, (lds_void_ptr)(vdst + c * 4096), 16, (int)v_goff, (int)(c * v_gstep), 0, 0);
   };
 
   // processing order of the key tiles (ping-pong per round of Q blocks, see attn_fwd.hip)
@@ -392,11 +373,10 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
     }
   };
 
-  auto compute_tile = [&](auto buf_tag, int j, auto masked_tag, auto exact_tag, auto prime_tag) __attribute__((always_inline)) {
+  auto compute_tile = [&](auto buf_tag, int j, auto masked_tag, auto exact_tag) __attribute__((always_inline)) {
     constexpr int BUF = decltype(buf_tag)::value;
     constexpr bool MASKED = decltype(masked_tag)::value;
     constexpr bool EXACT = decltype(exact_tag)::value || MASKED;
-    constexpr bool PRIME = decltype(prime_tag)::value;
     const char* kbuf = smem + BUF * KBYTES;
     float sc, c0;
     if constexpr (QK16) {
@@ -539,20 +519,12 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
     using R1 = std::integral_constant<int, 1>;
 
     static_for<0, 4>([&](auto kb) { compute_scores(kb); });
-    if constexpr (PRIME) {
-      raise_reference(0, lane_max(0), 0.0f);
-      raise_reference(1, lane_max(1), 0.0f);
-      return;
-    }
     c1[0] = c0 - m_run[0];  // exact (grid argument); +inf while m_run = -inf
     c1[1] = c0 - m_run[1];
-    bool dead = false;
     if constexpr (EXACT) {
       // Exact path: every tile tests its LANE-partial maxima against the reference - the exponent argument of the largest score
       // the lane holds, 2 x (8 v_max + 1 v_fma + 1 v_cmp) - and only a wave that finds a row more than 2^THR above its reference
-      // takes the cross-lane step and the rescale.  A wave whose 32 rows all lie more than 2^26 below their references has
-      // nothing to add: every P rounds to +0 in fp16 (P < 2^-25), so its exponentials and PV products are skipped - the
-      // accumulators would not change by a bit (finite V).
+      // takes the cross-lane step and the rescale.
       const float pm0 = lane_max(0), pm1 = lane_max(1);
       const float a0 = __builtin_fmaf(QK16 ? pm0 : pm0 - bias, sc, c1[0]), a1 = __builtin_fmaf(QK16 ? pm1 : pm1 - bias, sc, c1[1]);
       if (__any((a0 > THR) || (a1 > THR))) {  // also the first tile (c1 = +inf)
@@ -560,41 +532,37 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
         raise_reference(1, pm1, THR);
         c1[0] = c0 - m_run[0];
         c1[1] = c0 - m_run[1];
-      } else if (LBFA_DEAD_SKIP) {
-        dead = !__any((a0 > kDeadArg) || (a1 > kDeadArg));
       }
     }
-    if (__builtin_expect(!dead, 1)) {
-      if constexpr (!QK16) {
-        if (wide) {  // wave-uniform: scores as the integers themselves
+    if constexpr (!QK16) {
+      if (wide) {  // wave-uniform: scores as the integers themselves
 #pragma unroll
-          for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+          for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) x[rb][kb][e] -= kMagic;
-        }
+            for (int e = 0; e < 4; ++e) x[rb][kb][e] -= kMagic;
       }
-      static_for<0, (VD < NBT ? VD : NBT)>([&](auto b0) { v_issue(b0); });
-      exp_s(R0{}, R0{});
-      exp_s(R1{}, R0{});
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-      pv_s(R0{});
-      exp_s(R0{}, R1{});
-      exp_s(R1{}, R1{});
-      {
-        constexpr int NM = 2 * CB + 2;  // MFMAs of k-step 0: PV + row sums
-        constexpr int NV = 40 / NM;     // 16 fma + 16 exp + 8 cvt of k-step 1 spread over them
-        static_for<0, NM>([&](auto) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
-        });
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      pv_s(R1{});
-      __builtin_amdgcn_s_setprio(0);
     }
+    static_for<0, (VD < NBT ? VD : NBT)>([&](auto b0) { v_issue(b0); });
+    exp_s(R0{}, R0{});
+    exp_s(R1{}, R0{});
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    pv_s(R0{});
+    exp_s(R0{}, R1{});
+    exp_s(R1{}, R1{});
+    {
+      constexpr int NM = 2 * CB + 2;  // MFMAs of k-step 0: PV + row sums
+      constexpr int NV = 40 / NM;     // 16 fma + 16 exp + 8 cvt of k-step 1 spread over them
+      static_for<0, NM>([&](auto) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+      });
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    pv_s(R1{});
+    __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- tile loop -----------------------------------------------------------------------------------------------------
@@ -629,8 +597,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
     bool skip = false;
     if constexpr (decltype(masked_tag)::value && CAUSAL) skip = j * 64 > row0 + 31;  // all keys above all rows of this wave
     if constexpr (decltype(exact_tag)::value) skip = skip || i < skip_until;
-    if (!skip) compute_tile(buf_tag, j, masked_tag, exact_tag, No{});
-    store_tile(nbuf_tag);
+    if (!skip) compute_tile(buf_tag, j, masked_tag, exact_tag);
     if (vote) {
       const int bad = wave_overflowed();
       if (lane == 0) vote_flag[wave] = bad;
@@ -648,32 +615,38 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   auto run_tiles = [&](auto exact_tag, int i0) __attribute__((always_inline)) {
     constexpr bool EX = decltype(exact_tag)::value;
     int i = i0;
+    if constexpr (!EX) {
+      // lazy mode: the first tile takes the exact path - its row maxima become the reference - and every later full tile is
+      // exponentiated against the reference as it stands
+      if (n_main >= 2) {
+        step(B0{}, B1{}, 0, No{}, Yes{}, false);
+        if (step(B1{}, B0{}, 1, No{}, No{}, 2 < n_main)) return 2;
+        i = 2;
+      }
+    }
     for (; i + 1 < n_main; i += 2) {
       step(B0{}, B1{}, i, No{}, exact_tag, false);
       const int d = i + 2;
       const bool vote = !EX && (d & (d - 1)) == 0 && d < n_main;
       if (step(B1{}, B0{}, i + 1, No{}, exact_tag, vote)) return d;
     }
+    // i is even and at most one full tile is left (odd n_main): it takes the exact path in either mode (with n_main = 1 it is
+    // the tile that sets the reference); every tile after it is masked
     for (; i < n_tiles; i += 2) {
-      if (i < n_main) step(B0{}, B1{}, i, No{}, exact_tag, false);
-      else step(B0{}, B1{}, i, Yes{}, exact_tag, false);
-      if (i + 1 < n_tiles) {
-        if (i + 1 < n_main) step(B1{}, B0{}, i + 1, No{}, exact_tag, false);
-        else step(B1{}, B0{}, i + 1, Yes{}, exact_tag, false);
-      }
+      if (i < n_main) step(B0{}, B1{}, i, No{}, Yes{}, false);
+      else step(B0{}, B1{}, i, Yes{}, Yes{}, false);
+      if (i + 1 < n_tiles) step(B1{}, B0{}, i + 1, Yes{}, Yes{}, false);
     }
     return -1;
   };
   auto first_tile_landed = [&]() __attribute__((always_inline)) {
     refresh_scale_table(tile_of(0) & ~63);
-    store_tile(B0{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
 
   LBFA_STAMP(2);
   first_tile_landed();
-  if (n_main > 0) compute_tile(B0{}, tile_of(0), No{}, No{}, Yes{});  // reference <- exact row max of the first tile
   int replay_end = run_tiles(No{}, 0);
   LBFA_STAMP(3);
   int my_bad = 0;
@@ -738,31 +711,30 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
 #define LBFA_CAT(a, b) LBFA_CAT2(a, b)
 #define LBFA_DNAME(fn) LBFA_CAT(fn, LBFA_D16)
 
+// int8 Q and K codes, fp16 V (lbfa_attn_fwd: bf16 V is cast by the caller, as src/core.py:307-308 does before its kernel call)
 hipError_t LBFA_DNAME(launch16_attn_fwd_d)(const AttnParams& p, int v_dtype, int o_dtype, int causal, hipStream_t stream) {
+  if (v_dtype != LBFA_F16) return hipErrorInvalidValue;
   dim3 grid((unsigned)p.B * p.Hq * p.nQ), block(256);
-#define LBFA_A(VT, OT)                                                                                            \
-  do {                                                                                                            \
-    if (causal) hipLaunchKernelGGL((attn_fwd16_kernel<LBFA_D16, kQInt8, VT, OT, true>), grid, block, 0, stream, p);  \
-    else hipLaunchKernelGGL((attn_fwd16_kernel<LBFA_D16, kQInt8, VT, OT, false>), grid, block, 0, stream, p);        \
+#define LBFA_A(OT)                                                                                                    \
+  do {                                                                                                                \
+    if (causal) hipLaunchKernelGGL((attn_fwd16_kernel<LBFA_D16, kQInt8, LBFA_F16, OT, true>), grid, block, 0, stream, p);  \
+    else hipLaunchKernelGGL((attn_fwd16_kernel<LBFA_D16, kQInt8, LBFA_F16, OT, false>), grid, block, 0, stream, p);        \
   } while (0)
-#define LBFA_A2(VT)                                   \
-  do {                                                \
-    if (o_dtype == LBFA_F16) LBFA_A(VT, LBFA_F16);    \
-    else LBFA_A(VT, LBFA_BF16);                       \
-  } while (0)
-  if (v_dtype == LBFA_F16) LBFA_A2(LBFA_F16);
-  else LBFA_A2(LBFA_BF16);
-#undef LBFA_A2
+  if (o_dtype == LBFA_F16) LBFA_A(LBFA_F16);
+  else LBFA_A(LBFA_BF16);
 #undef LBFA_A
   return hipGetLastError();
 }
 
-hipError_t LBFA_DNAME(launch16_attn_fwd_qq_d)(const AttnParams& p, int dtype, int causal, hipStream_t stream) {
+// Q quantised in the kernel from its fp16 / bf16 source (dtype, also O's); V fp16 (the one-call operators cast a bf16 V in a
+// pre-pass: converting it on the way into LDS cost the kernel 9..10 % and 25..56 spilled registers)
+hipError_t LBFA_DNAME(launch16_attn_fwd_qq_d)(const AttnParams& p, int dtype, int v_dtype, int causal, hipStream_t stream) {
+  if (v_dtype != LBFA_F16) return hipErrorInvalidValue;
   dim3 grid((unsigned)p.B * p.Hq * p.nQ), block(256);
-#define LBFA_QQ(DT)                                                                                                    \
-  do {                                                                                                                 \
-    if (causal) hipLaunchKernelGGL((attn_fwd16_kernel<LBFA_D16, kQInt8, DT, DT, true, true>), grid, block, 0, stream, p); \
-    else hipLaunchKernelGGL((attn_fwd16_kernel<LBFA_D16, kQInt8, DT, DT, false, true>), grid, block, 0, stream, p);       \
+#define LBFA_QQ(DT)                                                                                                          \
+  do {                                                                                                                       \
+    if (causal) hipLaunchKernelGGL((attn_fwd16_kernel<LBFA_D16, kQInt8, LBFA_F16, DT, true, true>), grid, block, 0, stream, p); \
+    else hipLaunchKernelGGL((attn_fwd16_kernel<LBFA_D16, kQInt8, LBFA_F16, DT, false, true>), grid, block, 0, stream, p);       \
   } while (0)
   if (dtype == LBFA_F16) LBFA_QQ(LBFA_F16);
   else LBFA_QQ(LBFA_BF16);

@@ -17,7 +17,9 @@ hipError_t launch_quant_v_fp8(const void* v, int dtype, uint8_t* out, float* v_s
                               int d_valid, const int64_t* st, hipStream_t stream);
 hipError_t launch_attn_fwd(const AttnParams& p, int D, int v_dtype, int o_dtype, int causal, hipStream_t stream);
 hipError_t launch_attn_fwd_f16(const AttnParams& p, int D, int dtype, int causal, hipStream_t stream);
-hipError_t launch_attn_fwd_qq(const AttnParams& p, int D, int dtype, int v_fp8, int causal, hipStream_t stream);
+hipError_t launch_attn_fwd_qq(const AttnParams& p, int D, int dtype, int v_dtype, int causal, hipStream_t stream);
+hipError_t launch_cast_bf16_f16(const void* src, void* dst, int B, int H, int S, int d_valid, const int64_t* ss, const int64_t* ds,
+                                hipStream_t stream);
 }  // namespace lbfa
 
 namespace {
@@ -53,6 +55,10 @@ void dense_scale_layout(lbfa::AttnParams& p) {
 // zero padding of src/core.py:277-287 (never read, never written)
 bool head_dim_ok(int D) { return D >= 8 && D <= 128 && D % 8 == 0; }
 int padded_head_dim(int D) { return D <= 64 ? 64 : 128; }
+// The PV product of the int8 operators runs on fp16 MFMAs (the reference casts, src/core.py:307-308): a bf16 V is cast once, in a
+// pre-pass, into the workspace (4 bytes per element of HBM traffic: 1..6 % of the operator from S = 4K up; converting the tiles on
+// their way into LDS instead cost the attention kernel 9..10 % and 25..56 spilled registers).
+bool v_cast_prepass(int dtype, int D_padded, int pv_fp8) { (void)D_padded; return dtype == LBFA_BF16 && !pv_fp8; }
 }  // namespace
 
 namespace {
@@ -61,7 +67,7 @@ hipError_t launch_attention(const lbfa::AttnParams& p, int D, int v_dtype, int o
   const hipEvent_t e0 = g_prof_start, e1 = g_prof_stop;
   g_prof_start = g_prof_stop = nullptr;
   if (e0) (void)hipEventRecord(e0, stream);
-  const hipError_t err = quantise_q ? lbfa::launch_attn_fwd_qq(p, D, o_dtype, v_dtype == LBFA_E4M3, causal, stream)
+  const hipError_t err = quantise_q ? lbfa::launch_attn_fwd_qq(p, D, o_dtype, v_dtype, causal, stream)
                                     : lbfa::launch_attn_fwd(p, D, v_dtype, o_dtype, causal, stream);
   if (e1) (void)hipEventRecord(e1, stream);
   return err;
@@ -240,6 +246,16 @@ int lbfa_quant_v_fp8(const void* v, int dtype, uint8_t* v_fp8, float* v_scale, i
   return quant_v_fp8_impl(v, dtype, v_fp8, v_scale, B, H, S, D, D, strides_v, stream);
 }
 
+int lbfa_cast_bf16_to_f16(const void* src, void* dst, int B, int H, int S, int D, const int64_t strides_src[3],
+                          const int64_t strides_dst[3], void* stream) {
+  if (!src || !dst || !strides_src || !strides_dst) return fail(LBFA_EINVAL, "lbfa_cast_bf16_to_f16: null pointer");
+  if (B <= 0 || H <= 0 || S <= 0 || D <= 0 || D % 8 != 0) return fail(LBFA_EINVAL, "lbfa_cast_bf16_to_f16: bad shape (D must be a multiple of 8)");
+  if (!aligned16(src) || !aligned16(dst) || (strides_src[0] | strides_src[1] | strides_src[2] | strides_dst[0] | strides_dst[1] | strides_dst[2]) % 8 != 0)
+    return fail(LBFA_EINVAL, "lbfa_cast_bf16_to_f16: tensors must be 16-byte aligned, strides multiples of 8 elements");
+  g_err[0] = 0;
+  return check_hip(lbfa::launch_cast_bf16_f16(src, dst, B, H, S, D, strides_src, strides_dst, (hipStream_t)stream), "lbfa_cast_bf16_to_f16 launch");
+}
+
 int lbfa_attn_fwd(const int8_t* q, const int8_t* k, const void* v, int v_dtype, void* o, int o_dtype, float* lse,
                   const float* q_scale, const float* k_scale, const float* v_scale,
                   int B, int Hq, int Hkv, int Sq, int Sk, int D,
@@ -250,10 +266,12 @@ int lbfa_attn_fwd(const int8_t* q, const int8_t* k, const void* v, int v_dtype, 
   if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Sk <= 0) return fail(LBFA_EINVAL, "lbfa_attn_fwd: empty tensor");
   if (D != 64 && D != 128) return fail(LBFA_EINVAL, "Unsupported head_dim: %d", D);
   if (Hq % Hkv != 0) return fail(LBFA_EINVAL, "num_qo_heads (%d) must be divisible by num_kv_heads (%d)", Hq, Hkv);
-  if (v_dtype != LBFA_F16 && v_dtype != LBFA_BF16 && v_dtype != LBFA_E4M3) return fail(LBFA_EINVAL, "lbfa_attn_fwd: bad v_dtype %d", v_dtype);
+  if (v_dtype == LBFA_BF16)
+    return fail(LBFA_EINVAL, "lbfa_attn_fwd: v must be float16 (cast bfloat16 with lbfa_cast_bf16_to_f16, the `v.to(float16)` of the reference) or e4m3");
+  if (v_dtype != LBFA_F16 && v_dtype != LBFA_E4M3) return fail(LBFA_EINVAL, "lbfa_attn_fwd: bad v_dtype %d", v_dtype);
   if (o_dtype != LBFA_F16 && o_dtype != LBFA_BF16) return fail(LBFA_EINVAL, "lbfa_attn_fwd: bad o_dtype %d", o_dtype);
   if (v_dtype == LBFA_E4M3 && !v_scale) return fail(LBFA_EINVAL, "lbfa_attn_fwd: v_scale is required for fp8 V");
-  if (v_dtype != LBFA_E4M3 && !strides_v) return fail(LBFA_EINVAL, "lbfa_attn_fwd: strides_v is required for fp16/bf16 V");
+  if (v_dtype != LBFA_E4M3 && !strides_v) return fail(LBFA_EINVAL, "lbfa_attn_fwd: strides_v is required for fp16 V");
   if (is_causal && Sq != Sk) return fail(LBFA_EINVAL, "qo_len and kv_len must be equal for causal attention");
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (reinterpret_cast<uintptr_t>(o) & 7u))
     return fail(LBFA_EINVAL, "lbfa_attn_fwd: q/k/v must be 16-byte aligned and o 8-byte aligned");
@@ -301,9 +319,9 @@ int lbfa_attn_fwd(const int8_t* q, const int8_t* k, const void* v, int v_dtype, 
 namespace {
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct FwdLayout {
-  size_t km, part, q8, k8, qs, ks, corr, v8, vs, total;
+  size_t km, part, q8, k8, qs, ks, corr, v8, vs, v16, total;
 };
-FwdLayout fwd_layout(int B, int Hq, int Hkv, int Sq, int Sk, int D, int pv_fp8, int want_corr) {
+FwdLayout fwd_layout(int B, int Hq, int Hkv, int Sq, int Sk, int D, int pv_fp8, int want_corr, int dtype) {
   FwdLayout L;
   size_t o = 0;
   auto take = [&](size_t n) { size_t at = o; o += align256(n); return at; };
@@ -316,14 +334,18 @@ FwdLayout fwd_layout(int B, int Hq, int Hkv, int Sq, int Sk, int D, int pv_fp8, 
   L.ks = take((size_t)B * Hkv * ((Sk + LBFA_BLKK - 1) / LBFA_BLKK) * 4);
   L.v8 = take(pv_fp8 ? lbfa_v_fp8_bytes(B, Hkv, Sk, D) : 0);
   L.vs = take(pv_fp8 ? (size_t)B * Hkv * D * 4 : 0);
+  L.v16 = take(v_cast_prepass(dtype, D, pv_fp8) ? (size_t)B * Hkv * Sk * D * 2 : 0);  // fp16 copy of a bf16 V, [B,Hkv,Sk,D]
   L.total = o;
   return L;
 }
 }  // namespace
 
-size_t lbfa_forward_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int pv_fp8, int smooth_k, int return_lse) {
+size_t lbfa_forward_workspace_bytes_dt(int B, int Hq, int Hkv, int Sq, int Sk, int D, int dtype, int pv_fp8, int smooth_k, int return_lse) {
   if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Sk <= 0 || !head_dim_ok(D)) return 0;
-  return fwd_layout(B, Hq, Hkv, Sq, Sk, padded_head_dim(D), pv_fp8, smooth_k && return_lse).total;
+  return fwd_layout(B, Hq, Hkv, Sq, Sk, padded_head_dim(D), pv_fp8, smooth_k && return_lse, dtype).total;
+}
+size_t lbfa_forward_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int pv_fp8, int smooth_k, int return_lse) {
+  return lbfa_forward_workspace_bytes_dt(B, Hq, Hkv, Sq, Sk, D, LBFA_BF16, pv_fp8, smooth_k, return_lse);  // enough for either dtype
 }
 
 int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o, float* lse, void* workspace,
@@ -339,7 +361,7 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
   D = padded_head_dim(Dg);  // what the kernels run on; channels >= Dg are never read or written
   if (Hq % Hkv != 0) return fail(LBFA_EINVAL, "num_qo_heads (%d) must be divisible by num_kv_heads (%d)", Hq, Hkv);
   const int want_lse = lse != nullptr, want_corr = want_lse && smooth_k;
-  const FwdLayout L = fwd_layout(B, Hq, Hkv, Sq, Sk, D, pv_fp8, want_corr);
+  const FwdLayout L = fwd_layout(B, Hq, Hkv, Sq, Sk, D, pv_fp8, want_corr, dtype);
   if (workspace_bytes < L.total) return fail(LBFA_EINVAL, "lbfa_forward: workspace too small (%zu < %zu)", workspace_bytes, L.total);
   if (!aligned16(workspace)) return fail(LBFA_EINVAL, "lbfa_forward: workspace must be 16-byte aligned");
   // Every argument check comes BEFORE the first launch: a call that returns LBFA_EINVAL has enqueued nothing (no wasted
@@ -394,13 +416,22 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
     v_dtype = LBFA_E4M3;
     v_scale = (const float*)(ws + L.vs);
   }
+  int64_t sv[3] = {strides_v[0], strides_v[1], strides_v[2]};
+  if (v_cast_prepass(dtype, D, pv_fp8)) {
+    const int64_t sv16[3] = {(int64_t)Hkv * Sk * D, (int64_t)Sk * D, D};
+    st = check_hip(lbfa::launch_cast_bf16_f16(v, ws + L.v16, B, Hkv, Sk, Dg, strides_v, sv16, (hipStream_t)stream), "lbfa_forward (V cast) launch");
+    if (st) return st;
+    v_in = ws + L.v16;
+    v_dtype = LBFA_F16;
+    sv[0] = sv16[0]; sv[1] = sv16[1]; sv[2] = sv16[2];
+  }
   // attention, with the LSE fix-up of src/core.py:344-350 fused into the epilogue
   lbfa::AttnParams p;
   p.q = (const int8_t*)q; p.k = k8; p.v = v_in; p.o = o; p.lse = lse;
   p.q_scale = nullptr; p.k_scale = ks; p.v_scale = v_scale;
   p.qb = strides_q[0]; p.qh = strides_q[1]; p.qs = strides_q[2];
   p.kb = sk8[0]; p.kh = sk8[1]; p.ks = sk8[2];
-  if (v_dtype != LBFA_E4M3) { p.vb = strides_v[0]; p.vh = strides_v[1]; p.vs = strides_v[2]; }
+  if (v_dtype != LBFA_E4M3) { p.vb = sv[0]; p.vh = sv[1]; p.vs = sv[2]; }
   else { p.vb = p.vh = p.vs = 0; }
   p.ob = strides_o[0]; p.oh = strides_o[1]; p.os = strides_o[2];
   p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Sq = Sq; p.Sk = Sk;
@@ -487,7 +518,7 @@ int attn_varlen_core(const char* who, const int8_t* q, const int8_t* k, const vo
   if (B <= 0 || Hq <= 0 || Hkv <= 0 || max_q <= 0 || max_k <= 0) return fail(LBFA_EINVAL, "%s: empty batch", who);
   if (D != 64 && D != 128) return fail(LBFA_EINVAL, "Unsupported head_dim: %d", D);
   if (Hq % Hkv != 0) return fail(LBFA_EINVAL, "num_qo_heads (%d) must be divisible by num_kv_heads (%d)", Hq, Hkv);
-  if (v_dtype != LBFA_F16 && v_dtype != LBFA_BF16) return fail(LBFA_EINVAL, "%s: v must be float16 or bfloat16", who);
+  if (v_dtype != LBFA_F16) return fail(LBFA_EINVAL, "%s: v must be float16 (cast bfloat16 with lbfa_cast_bf16_to_f16)", who);
   if (o_dtype != LBFA_F16 && o_dtype != LBFA_BF16) return fail(LBFA_EINVAL, "%s: bad o_dtype %d", who, o_dtype);
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (reinterpret_cast<uintptr_t>(o) & 7u))
     return fail(LBFA_EINVAL, "%s: q/k/v must be 16-byte aligned and o 8-byte aligned", who);
@@ -528,9 +559,9 @@ int attn_varlen_core(const char* who, const int8_t* q, const int8_t* k, const vo
 }
 
 struct VarlenLayout {
-  size_t km, part, q8, k8, qs, ks, total;
+  size_t km, part, q8, k8, qs, ks, v16, total;
 };
-VarlenLayout varlen_layout(int B, int Hq, int Hkv, int total_q, int total_k, int max_q, int max_k, int D) {
+VarlenLayout varlen_layout(int B, int Hq, int Hkv, int total_q, int total_k, int max_q, int max_k, int D, int dtype) {
   VarlenLayout L;
   size_t o = 0;
   auto take = [&](size_t n) { size_t at = o; o += align256(n); return at; };
@@ -540,6 +571,7 @@ VarlenLayout varlen_layout(int B, int Hq, int Hkv, int total_q, int total_k, int
   L.q8 = L.qs = 0;
   L.k8 = take((size_t)total_k * Hkv * D);
   L.ks = take((size_t)B * Hkv * ((max_k + LBFA_BLKK - 1) / LBFA_BLKK) * 4);
+  L.v16 = take(v_cast_prepass(dtype, D, 0) ? (size_t)total_k * Hkv * D * 2 : 0);  // fp16 copy of a bf16 V, [total_k,Hkv,D]
   L.total = o;
   return L;
 }
@@ -557,10 +589,14 @@ int lbfa_attn_fwd_varlen(const int8_t* q, const int8_t* k, const void* v, int v_
                           strides_v, strides_o, is_causal, stream);
 }
 
+size_t lbfa_forward_varlen_workspace_bytes_dt(int B, int Hq, int Hkv, int total_q, int total_k, int max_seqlen_q,
+                                              int max_seqlen_k, int D, int dtype) {
+  if (B <= 0 || Hq <= 0 || Hkv <= 0 || total_q <= 0 || total_k <= 0 || max_seqlen_q <= 0 || max_seqlen_k <= 0 || !head_dim_ok(D)) return 0;
+  return varlen_layout(B, Hq, Hkv, total_q, total_k, max_seqlen_q, max_seqlen_k, padded_head_dim(D), dtype).total;
+}
 size_t lbfa_forward_varlen_workspace_bytes(int B, int Hq, int Hkv, int total_q, int total_k, int max_seqlen_q,
                                            int max_seqlen_k, int D) {
-  if (B <= 0 || Hq <= 0 || Hkv <= 0 || total_q <= 0 || total_k <= 0 || max_seqlen_q <= 0 || max_seqlen_k <= 0 || !head_dim_ok(D)) return 0;
-  return varlen_layout(B, Hq, Hkv, total_q, total_k, max_seqlen_q, max_seqlen_k, padded_head_dim(D)).total;
+  return lbfa_forward_varlen_workspace_bytes_dt(B, Hq, Hkv, total_q, total_k, max_seqlen_q, max_seqlen_k, D, LBFA_BF16);  // enough for either dtype
 }
 
 int lbfa_forward_varlen(const void* q, const void* k, const void* v, int dtype, void* o,
@@ -577,7 +613,7 @@ int lbfa_forward_varlen(const void* q, const void* k, const void* v, int dtype, 
   if (!head_dim_ok(Dg)) return fail(LBFA_EINVAL, "Unsupported head_dim: %d", Dg);
   D = padded_head_dim(Dg);
   if (Hq % Hkv != 0) return fail(LBFA_EINVAL, "num_qo_heads (%d) must be divisible by num_kv_heads (%d)", Hq, Hkv);
-  const VarlenLayout L = varlen_layout(B, Hq, Hkv, total_q, total_k, max_seqlen_q, max_seqlen_k, D);
+  const VarlenLayout L = varlen_layout(B, Hq, Hkv, total_q, total_k, max_seqlen_q, max_seqlen_k, D, dtype);
   if (workspace_bytes < L.total) return fail(LBFA_EINVAL, "lbfa_forward_varlen: workspace too small (%zu < %zu)", workspace_bytes, L.total);
   if (!aligned16(workspace)) return fail(LBFA_EINVAL, "lbfa_forward_varlen: workspace must be 16-byte aligned");
   // every argument check before the first launch (see lbfa_forward)
@@ -611,8 +647,19 @@ int lbfa_forward_varlen(const void* q, const void* k, const void* v, int dtype, 
   st = quant_varlen_core("lbfa_forward_varlen (K)", k, dtype, km, 1, k8, ks, cu_seqlens_k, nullptr, 1.0f, k_qmax, LBFA_BLKK, B,
                          max_seqlen_k, Hkv, D, Dg, strides_k, sk8, stream);
   if (st) return st;
-  return attn_varlen_core("lbfa_forward_varlen", (const int8_t*)q, k8, v, dtype, o, dtype, nullptr, ks, cu_seqlens_q, cu_seqlens_k,
-                          nullptr, nullptr, B, Hq, Hkv, max_seqlen_q, max_seqlen_k, D, Dg, strides_q, sk8, strides_v, strides_o,
+  const void* v_in = v;
+  int v_dtype = dtype;
+  int64_t sv[2] = {strides_v[0], strides_v[1]};
+  if (v_cast_prepass(dtype, D, 0)) {
+    const int64_t src3[3] = {0, strides_v[0], strides_v[1]}, dst3[3] = {0, D, (int64_t)Hkv * D};
+    st = check_hip(lbfa::launch_cast_bf16_f16(v, ws + L.v16, 1, Hkv, total_k, Dg, src3, dst3, (hipStream_t)stream), "lbfa_forward_varlen (V cast) launch");
+    if (st) return st;
+    v_in = ws + L.v16;
+    v_dtype = LBFA_F16;
+    sv[0] = D; sv[1] = (int64_t)Hkv * D;
+  }
+  return attn_varlen_core("lbfa_forward_varlen", (const int8_t*)q, k8, v_in, v_dtype, o, dtype, nullptr, ks, cu_seqlens_q, cu_seqlens_k,
+                          nullptr, nullptr, B, Hq, Hkv, max_seqlen_q, max_seqlen_k, D, Dg, strides_q, sk8, sv, strides_o,
                           is_causal, stream, true, (float)(sm_scale * 1.44269504), q_qmax);
 }
 

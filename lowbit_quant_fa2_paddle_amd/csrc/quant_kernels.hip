@@ -365,6 +365,33 @@ __global__ __launch_bounds__(256) void v_encode_kernel(VFp8Params p) {
   }
 }
 
+// bf16 -> fp16 of a [B, H, S, D] tensor (16 bytes per thread and step): the `v.to(float16)` of src/core.py:307-308 for the
+// operators whose PV product runs on fp16 MFMAs.  HBM-bound, 4 bytes per element.
+struct CastParams {
+  const unsigned short* src;
+  unsigned short* dst;
+  int64_t sb, sh, ss, db, dh, ds;
+  int B, H, S, cpr;  // cpr = 16-byte chunks per row (the valid head dim / 8)
+};
+__global__ __launch_bounds__(256) void cast_bf16_f16_kernel(CastParams p) {
+  const int64_t n = (int64_t)p.B * p.H * p.S * p.cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % p.cpr);
+    int64_t r = i / p.cpr;
+    const int s = (int)(r % p.S);
+    r /= p.S;
+    const int h = (int)(r % p.H), b = (int)(r / p.H);
+    const uint4 raw = *reinterpret_cast<const uint4*>(p.src + b * p.sb + h * p.sh + s * p.ss + c * 8);
+    unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const f16x2 pk = f16x2{(_Float16)__uint_as_float(w[e] << 16), (_Float16)__uint_as_float(w[e] & 0xffff0000u)};
+      w[e] = __builtin_bit_cast(unsigned, pk);
+    }
+    *reinterpret_cast<uint4*>(p.dst + b * p.db + h * p.dh + s * p.ds + c * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
 }  // namespace lbfa
 
 // ---------------------------------------------------------------------------------------------------
@@ -453,6 +480,19 @@ hipError_t launch_quant_v_fp8(const void* v, int dtype, uint8_t* out, float* v_s
   if (dtype == LBFA_F16) { if (D == 64) { LBFA_V(LBFA_F16, 64); } else { LBFA_V(LBFA_F16, 128); } }
   else { if (D == 64) { LBFA_V(LBFA_BF16, 64); } else { LBFA_V(LBFA_BF16, 128); } }
 #undef LBFA_V
+  return hipGetLastError();
+}
+
+hipError_t launch_cast_bf16_f16(const void* src, void* dst, int B, int H, int S, int d_valid, const int64_t* ss, const int64_t* ds,
+                                hipStream_t stream) {
+  CastParams p;
+  p.src = (const unsigned short*)src; p.dst = (unsigned short*)dst;
+  p.sb = ss[0]; p.sh = ss[1]; p.ss = ss[2];
+  p.db = ds[0]; p.dh = ds[1]; p.ds = ds[2];
+  p.B = B; p.H = H; p.S = S; p.cpr = d_valid / 8;
+  const int64_t n = (int64_t)B * H * S * p.cpr;
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 256 * 64 ? (n + 255) / 256 : 256 * 64);
+  hipLaunchKernelGGL(cast_bf16_f16_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
 

@@ -100,7 +100,20 @@ def test_one_call_and_varlen_validation(lib):
     st = lib.lbfa_quant_per_block_varlen(p, 0, None, 1, p, p, p, None, 1.0, 127, 128, 2, 8, 2, 64, s2, s2, None)
     assert st == _lib.LBFA_EINVAL and b"null pointer" in lib.lbfa_last_error()
     st = lib.lbfa_attn_fwd_varlen(p, p, p, 2, p, 0, p, p, p, p, p, p, 2, 2, 2, 8, 8, 64, s2, s2, s2, s2, 0, None)
-    assert st == _lib.LBFA_EINVAL and b"float16 or bfloat16" in lib.lbfa_last_error()
+    assert st == _lib.LBFA_EINVAL and b"v must be float16" in lib.lbfa_last_error()
+    # the attention entry points take fp16 (or e4m3) V, as the reference's kernel does: bf16 is cast first (src/core.py:307-308)
+    st = lib.lbfa_attn_fwd_varlen(p, p, p, 1, p, 0, p, p, p, p, p, p, 2, 2, 2, 8, 8, 64, s2, s2, s2, s2, 0, None)
+    assert st == _lib.LBFA_EINVAL and b"lbfa_cast_bf16_to_f16" in lib.lbfa_last_error()
+    st = lib.lbfa_attn_fwd(p, p, p, 1, p, 0, None, p, p, None, 1, 2, 2, 8, 8, 64, s3, s3, s3, s3, 0, None)
+    assert st == _lib.LBFA_EINVAL and b"lbfa_cast_bf16_to_f16" in lib.lbfa_last_error()
+    st = lib.lbfa_cast_bf16_to_f16(p, p, 1, 2, 8, 36, s3, s3, None)
+    assert st == _lib.LBFA_EINVAL and b"multiple of 8" in lib.lbfa_last_error()
+    # a bf16 V is cast into the workspace (not for fp8 PV, whose V quantiser reads bf16 itself): the dtype-aware size is larger
+    f16, bf16 = _lib.LBFA_F16, _lib.LBFA_BF16
+    assert lib.lbfa_forward_workspace_bytes_dt(1, 2, 2, 8, 8, 128, bf16, 0, 1, 0) > lib.lbfa_forward_workspace_bytes_dt(1, 2, 2, 8, 8, 128, f16, 0, 1, 0)
+    assert lib.lbfa_forward_workspace_bytes_dt(1, 2, 2, 8, 8, 64, bf16, 1, 1, 0) == lib.lbfa_forward_workspace_bytes_dt(1, 2, 2, 8, 8, 64, f16, 1, 1, 0)
+    assert lib.lbfa_forward_workspace_bytes(1, 2, 2, 8, 8, 128, 0, 1, 0) == lib.lbfa_forward_workspace_bytes_dt(1, 2, 2, 8, 8, 128, bf16, 0, 1, 0)
+    assert lib.lbfa_forward_varlen_workspace_bytes_dt(2, 2, 2, 16, 16, 8, 8, 128, bf16) > lib.lbfa_forward_varlen_workspace_bytes_dt(2, 2, 2, 16, 16, 8, 8, 128, f16)
     # un-quantised kernel
     st = lib.lbfa_sdpa_fwd(p, p, p, 0, p, None, 1, 2, 2, 8, 16, 64, s3, s3, s3, s3, 0.125, 1, None)
     assert st == _lib.LBFA_EINVAL and b"qo_len and kv_len must be equal" in lib.lbfa_last_error()

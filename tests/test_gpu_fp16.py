@@ -1,8 +1,9 @@
 """GPU tests of the un-quantised attention kernel (`lbfa_sdpa_fwd`, the FP16 branch of the precision router,
 src/core.py:1066-1096) against fp32 SDPA on the same fp16 / bf16 inputs (oracle.sdpa_naive, src/core.py:46-69).
 
-Tolerance: the kernel rounds P to fp16 before the PV product (as the low-bit kernels and FlashAttention-2 do) and
-the output to fp16 / bf16: |dO| <= 2e-3 + 2e-3 |O| (bf16 output adds 2^-7 relative); LSE <= 1e-3."""
+Tolerance: the kernel rounds P to the input dtype before the PV product (as FlashAttention-2 does: fp16 P x fp16 V, bf16 P x
+bf16 V on the bf16 MFMA) and the output to fp16 / bf16: |dO| <= 2e-3 + 2e-3 |O| (bf16 output adds 2^-7 relative); the row sums
+ride on the same MFMA, i.e. over the rounded P: LSE <= 1e-3 (fp16; one fp16 rounding of a lone P is 4.9e-4) / 2.5e-3 (bf16: 2e-3)."""
 import numpy as np
 import pytest
 
@@ -30,7 +31,7 @@ def test_fp16_kernel_vs_fp32_sdpa(oracle, dev, dtype, layout, causal, B, H, Hkv,
     ref, rlse = oracle.sdpa_naive(*(_canon(a, layout).astype(np.float64) for a in (q, k, v)), is_causal=causal,
                                   sm_scale=D ** -0.5, return_lse=True)
     _o_close(_canon(_np(o), layout), ref, dtype)
-    assert np.abs(_np(lse) - rlse).max() <= 1e-3
+    assert np.abs(_np(lse) - rlse).max() <= (1e-3 if dtype == "fp16" else 2.5e-3)
 
 
 def test_fp16_kernel_large_scores_and_router(oracle, dev):

@@ -204,11 +204,13 @@ def check_tr_reads(ins: list) -> list:
 
 
 def scratch_in_loops(ins: list) -> int:
-    """number of scratch_* instructions inside loop bodies (address ranges closed by a backward branch) of one function"""
-    spans = [(tgt, a) for (a, mn, _, tgt) in ins if (mn.startswith("s_cbranch") or mn == "s_branch") and tgt is not None and tgt <= a]
+    """number of scratch_* instructions inside the INNERMOST loops of one function (address ranges closed by a backward branch
+    that contain no other such range: the unrolled tile loops of the attention kernels, not the replay around them)"""
+    spans = sorted({(tgt, a) for (a, mn, _, tgt) in ins if (mn.startswith("s_cbranch") or mn == "s_branch") and tgt is not None and tgt <= a})
+    inner = [(lo, hi) for (lo, hi) in spans if not any((lo2, hi2) != (lo, hi) and lo <= lo2 and hi2 <= hi for (lo2, hi2) in spans)]
     n = 0
     for a, mn, _, _ in ins:
-        if mn.startswith("scratch_") and any(lo <= a <= hi for lo, hi in spans):
+        if mn.startswith("scratch_") and any(lo <= a <= hi for lo, hi in inner):
             n += 1
     return n
 

@@ -673,6 +673,8 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
 
   LBFA_STAMP(4);
   // ---- epilogue: O = O^T / l, LSE ------------------------------------------------------------------------------
+  // (8-byte stores per lane, the four g-lanes of a row on one 32-byte sector.  Staging O through LDS into whole-row dwordx4
+  // stores measured no faster: C2 +0.1 %, causal S4K -0.7 %, D128 0 %.)
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
     const int qrow = qrow_of(rb);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Markdown table of DESIGN.md section 3.1 from a bench.py JSON line (default profiles/r02_bench_line.json)."""
+"""Markdown table of DESIGN.md section 3.1 from a bench.py JSON line (default profiles/r03_bench_line.json)."""
 import json, sys
-d = json.loads(open(sys.argv[1] if len(sys.argv) > 1 else "profiles/r02_bench_line.json").read().strip().splitlines()[-1])
+d = json.loads(open(sys.argv[1] if len(sys.argv) > 1 else "profiles/r03_bench_line.json").read().strip().splitlines()[-1])
 f = d["fa2_reference"]
 print("| workload (B4 H32, N(0,1) fp16 inputs) | whole op | attention kernel | frac of roof | torch FA2 | own fp16 | whole / torch FA2 | whole / own fp16 |")
 print("|---|---|---|---|---|---|---|---|")

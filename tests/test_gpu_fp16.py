@@ -2,7 +2,7 @@
 src/core.py:1066-1096) against fp32 SDPA on the same fp16 / bf16 inputs (oracle.sdpa_naive, src/core.py:46-69).
 
 Tolerance: the kernel rounds P to the input dtype before the PV product (as FlashAttention-2 does: fp16 P x fp16 V, bf16 P x
-bf16 V on the bf16 MFMA) and the output to fp16 / bf16: |dO| <= 2e-3 + 2e-3 |O| (bf16 output adds 2^-7 relative); the row sums
+bf16 V on the bf16 MFMA) and the output to fp16 / bf16: |dO| <= 2e-3 + 2e-3 |O| (bf16: 4e-3 + (2e-3 + 2^-7) |O|, P carries 2^-9); the row sums
 ride on the same MFMA, i.e. over the rounded P: LSE <= 1e-3 (fp16; one fp16 rounding of a lone P is 4.9e-4) / 2.5e-3 (bf16: 2e-3)."""
 import numpy as np
 import pytest
@@ -30,7 +30,7 @@ def test_fp16_kernel_vs_fp32_sdpa(oracle, dev, dtype, layout, causal, B, H, Hkv,
     assert o.dtype == TDT[dtype] and tuple(o.shape) == q.shape
     ref, rlse = oracle.sdpa_naive(*(_canon(a, layout).astype(np.float64) for a in (q, k, v)), is_causal=causal,
                                   sm_scale=D ** -0.5, return_lse=True)
-    _o_close(_canon(_np(o), layout), ref, dtype)
+    _o_close(_canon(_np(o), layout), ref, dtype, atol=2e-3 if dtype == "fp16" else 4e-3)
     assert np.abs(_np(lse) - rlse).max() <= (1e-3 if dtype == "fp16" else 2.5e-3)
 
 
@@ -69,4 +69,4 @@ def test_bf16_inputs_keep_their_range(oracle, dev):
     o = core.flash_attn_fp16(tq, tk, tv)
     assert torch.isfinite(o).all()
     ref = oracle.sdpa_naive(*(a.astype(np.float64) for a in (q, k, v)), sm_scale=64 ** -0.5)
-    _o_close(_np(o), ref, "bf16")
+    _o_close(_np(o), ref, "bf16", atol=4e-3)

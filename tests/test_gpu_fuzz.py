@@ -80,7 +80,9 @@ def test_fuzz_unquantised_and_varlen(oracle, dev, seed):
         o = lb.core.flash_attn_fp16(tq, tk, tv, tensor_layout=c["layout"], is_causal=c["causal"], sm_scale=c["sm_scale"])
         ref = oracle.sdpa_naive(*(_canon(a, c["layout"]).astype(np.float64) for a in (q, k, v)), is_causal=c["causal"],
                                 sm_scale=c["sm_scale"] or c["D"] ** -0.5)
-        _o_close(_canon(_np(o), c["layout"]), ref, c["dtype"])
+        # bf16 inputs: P and V stay bf16 on the bf16 MFMA (as a bf16 FlashAttention-2): P carries 2^-9, so an output can land one
+        # bf16 ulp off even at the bottom of its binade (2^-7 of the value) - twice the absolute slack of the fp16 kernel
+        _o_close(_canon(_np(o), c["layout"]), ref, c["dtype"], atol=4e-3 if c["dtype"] == "bf16" else 2e-3)
     else:  # packed batch vs the varlen oracle
         n = int(rng.integers(1, 5))
         lens_q = [int(x) for x in rng.choice([1, 5, 64, 100, 128, 129, 250, 320], size=n)]

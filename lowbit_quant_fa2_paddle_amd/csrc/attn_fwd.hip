@@ -25,39 +25,21 @@
 
 namespace lbfa {
 
-#ifndef LBFA_PRIO_FP8
-#define LBFA_PRIO_FP8 0  // s_setprio(1) around the 2 / 4 long block-scaled MFMAs of a tile: measured best without (+2.7 % C5, +4 % D=64)
-#endif
+// (s_setprio(1) around the 2 / 4 long block-scaled MFMAs of a tile measured worse than none: -2.7 % C5, -4 % D = 64)
 // Non-causal: every other ROUND of Q blocks of a head (a round = the workgroups one XCD runs at a time) walks the key tiles
 // from the last one down.  The K + V panel of a head (6..8 MB at S = 16K..32K) does not fit the XCD's 4 MB L2, so every round
 // streams it again; walking back, a round starts on the tiles the previous round has just left in the L2.  The direction
 // depends on the Q block index only (not on what else is in the launch): results do not depend on the batch composition.
-#ifndef LBFA_PINGPONG
-#define LBFA_PINGPONG 1
-#endif
 // fp8 PV: O^T += V^T P^T with ONE v_mfma_scale_f32_32x32x64_f8f6f4 per 32 channels and 64-key tile (e4m3 operands, unit
 // block scales: twice the fp16 MFMA rate) - must match the V layout written by lbfa_quant_v_fp8 (quant_kernels.hip)
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-#ifdef LBFA_STAMPS  // diagnostic build only: where does a workgroup's time go (s_memtime at five points, wave 0 lane 0)
-__device__ long long g_stamps[8192 * 8];
-#define LBFA_STAMP(k)                                                                                             \
-  do {                                                                                                            \
-    if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();     \
-  } while (0)
-extern "C" int lbfa_debug_stamps(void* dst) {
-  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), sizeof(g_stamps), 0, hipMemcpyDeviceToHost);
-}
-#else
-#define LBFA_STAMP(k)
-#endif
 
 // OT = dtype of O (and of the Q source when QQ): int8 Q / K codes, e4m3 V; QQ = Q is quantised inside the kernel
 template <int D, int OT, bool CAUSAL, bool QQ = false>
 // D = 64 fits three waves per SIMD (<= 168 registers): ask for it, or an instance one register over silently drops to two
 __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnParams p) {
   constexpr int RB = D;                              // bytes per K row
-  constexpr int PRIO = LBFA_PRIO_FP8;
   constexpr int KS = RB / 32;                        // k-steps of the score product (32 int8 per MFMA)
   constexpr int DB = D / 32;                         // 32-channel blocks of O^T
   constexpr int KBYTES = 64 * RB;                    // K tile
@@ -69,7 +51,6 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
   // buffers + 16 bytes for the workgroup reduction (block amax), which must not alias a tile in flight
   __shared__ __attribute__((aligned(16))) char smem[TILES_BYTES + 16];
 
-  LBFA_STAMP(0);
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -153,7 +134,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
 
   // processing order of the key tiles: i-th tile processed = tile_of(i)
   constexpr int kRound = 64;
-  const bool rev = !CAUSAL && (LBFA_PINGPONG != 0) && ((Sk & 63) == 0) && (((qt / kRound) & 1) != 0);  // workgroup-uniform
+  const bool rev = !CAUSAL && ((Sk & 63) == 0) && (((qt / kRound) & 1) != 0);  // workgroup-uniform
   auto tile_of = [&](int i) __attribute__((always_inline)) { return rev ? nK - 1 - i : i; };
   load_tile(tile_of(0), std::integral_constant<int, 0>{});  // first K / V tile: in flight while Q is fetched (and quantised)
   // ... and so are the dequantisation scales of the first 64 key tiles (lane l: tile l), needed right after the Q prologue
@@ -247,7 +228,6 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
     }
     qsc = p.q_scale[qsc_base + (int64_t)h * p.qsc_h + (int64_t)qt * p.qsc_blk];
   }
-  LBFA_STAMP(1);
 
   int n_tiles = nK;
   if constexpr (CAUSAL) n_tiles = min(nK, 2 * (qt + 1));
@@ -388,7 +368,6 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
       }
     }
     __builtin_amdgcn_sched_barrier(0);  // phase fence: keeps the V fragment reads and the row-sum adds where they are (registers)
-    if constexpr (PRIO & 2) __builtin_amdgcn_s_setprio(1);
     l_run += psum;
     // -- O^T += V^T P^T: e4m3 x e4m3 (cbsz = blgp = 0), E8M0 block scales 0x7F = 2^0
     static_for<0, DB>([&](auto i) {
@@ -410,7 +389,6 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
     asm volatile("s_nop %0" ::"n"(LBFA_MX_NOP));
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    if constexpr (PRIO & 2) __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- tile loop: one barrier per tile, buffers alternate statically (loop unrolled by two).
@@ -434,7 +412,6 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
     __syncthreads();  // with LDS-DMA in flight this waits vmcnt(0) first: tile j + 1 has landed when the barrier opens
   };
 
-  LBFA_STAMP(2);
   refresh_scale_table(tile_of(0) & ~63);
   __syncthreads();
   {
@@ -453,10 +430,8 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
       }
     }
   }
-  LBFA_STAMP(3);
   const float l_tot = half_swap_sum(l_run);
 
-  LBFA_STAMP(4);
   // ---- epilogue: O = O^T / l x v_scale, LSE ------------------------------------------------------------
   const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;  // a sequence without keys (packed batches only) yields zeros
   if (qrow < Sq) {
@@ -485,7 +460,6 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
       p.lse[li] = ls;
     }
   }
-  LBFA_STAMP(5);
 }
 
 // ---- launchers: every fp16-P variant runs in attn_fwd16.hip, fp8 PV here ------------------------------------------

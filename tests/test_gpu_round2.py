@@ -169,14 +169,17 @@ def test_p_to_e4m3_conversion_bit_exact(oracle, dev):
 
 
 @pytest.mark.parametrize("D,S,first_rev_row", [(64, 13312, 12288), (128, 8448, 8192)])
-@pytest.mark.parametrize("variant", ["fp16", "fp8"])
+@pytest.mark.parametrize("variant", ["fp16", "fp8", "fp16_peaky"])
 def test_reversed_rounds_of_q_blocks_vs_oracle(oracle, dev, D, S, first_rev_row, variant):
     """Non-causal kernels walk the key tiles backwards for every other ROUND of Q blocks of a head (ping-pong order for L2
     reuse, `tile_of` in attn_fwd16.hip / attn_fwd.hip): Q blocks >= 96 (D = 64) / >= 64 (D = 128).  The rows of the first reversed round - with
     more than 64 key tiles, so the per-64-tile scale table is refreshed downwards too - against the oracle, and a forward
-    block next to them for contrast.  (fp8 at D = 64 keeps 64-block rounds.)"""
+    block next to them for contrast.  (fp8 at D = 64 keeps 64-block rounds.)  `fp16_peaky`: queries x 6 - scores 8 binades wide,
+    so Q blocks of both directions overflow their lazy pass at some vote and replay in exact mode (round 3)."""
     import lowbit_quant_fa2_paddle_amd as lb
     q, k, v = oracle.make_inputs(1, 1, S, D, seed=23, k_bias=0.3)
+    if variant == "fp16_peaky":
+        q, variant = oracle.to_storage(q * 6.0, "fp16"), "fp16"
     tq, tk, tv = (_t(x, "fp16", dev) for x in (q, k, v))
     fn = lb.lowbit_fa_qk_int8_pv_fp16_triton if variant == "fp16" else lb.lowbit_fa_qk_int8_pv_fp8_cuda
     o, lse = fn(tq, tk, tv, return_lse=True)

@@ -75,10 +75,13 @@ def _pipelined_batch_gather(fn, qs, ks, vs, tensor_layout, world, group, kwargs)
     """Batch-sharded run with the gather issued behind the compute: the local shard is processed one batch element at a
     time, and each finished element is all-gathered asynchronously (RCCL works on its own stream) while the next element's
     kernels run.  Every element goes through `all_gather_into_tensor` on a contiguous [world, ...] staging slice (no list
-    form: RCCL then needs no flatten / copy-out pass and the stream semantics stay simple); one transposing copy at the
-    end puts the result in rank-major batch order (= the unsharded order).  Needs equal shards.
-    UNMEASURED on hardware so far (no multi-GPU node was available to rounds 1-2): the expectation - on the xGMI mesh a
-    direct all-gather moves one peer's piece per link, so only the last element's gather is exposed - is an expectation."""
+    form: RCCL then needs no flatten / copy-out pass and the stream semantics stay simple).  With more than one element per
+    rank the staging is [nb, world, ...] and ONE transposing copy at the end - a read and a write of the whole gathered output,
+    1.07 GB x world at C5 - puts the result in rank-major batch order (= the unsharded order); with one element per rank the
+    staging IS the result and no copy is made.  Needs equal shards.
+    UNMEASURED on hardware so far (no multi-GPU node was available to rounds 1-3): the expectation - on the xGMI mesh a
+    direct all-gather moves one peer's piece per link, so only the last element's gather is exposed - is an expectation, and
+    whether the copy costs more than the overlap returns is to be timed with `bench.py --gpus N` (`c5_strong.allgather_ms`)."""
     import torch
     import torch.distributed as dist
     nb = qs.shape[0]
@@ -91,6 +94,8 @@ def _pipelined_batch_gather(fn, qs, ks, vs, tensor_layout, world, group, kwargs)
         handles.append(dist.all_gather_into_tensor(out[i], o_i.contiguous(), group=group, async_op=True))
     for h in handles:
         h.wait()
+    if nb == 1:  # [1, world, ...] is already rank-major: a view, no copy
+        return out.reshape((world,) + tuple(out.shape[2:]))
     return out.transpose(0, 1).reshape((world * nb,) + tuple(out.shape[2:]))
 
 

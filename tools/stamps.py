@@ -11,11 +11,12 @@ from lowbit_quant_fa2_paddle_amd import _lib
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 B, H = 4, 32
+CAUSAL = len(sys.argv) > 3 and sys.argv[3] == "causal"
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(0)
 q, k, v = (torch.randn((B, H, S, D), generator=g, device=dev).half() for _ in range(3))
 for _ in range(5):
-    o = lb.sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout="HND", is_causal=False)
+    o = lb.sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout="HND", is_causal=CAUSAL)
 torch.cuda.synchronize()
 lib = _lib.load()
 buf = np.zeros(8192 * 8, dtype=np.int64)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LBFA_VERSION 100 /* 0.1.0 */
+#define LBFA_VERSION 110 /* 0.1.1: + lbfa_cast_bf16_to_f16, *_workspace_bytes_dt; lbfa_attn_fwd[_varlen] take fp16 / e4m3 V only */
 
 /* element types */
 #define LBFA_F16 0

@@ -119,8 +119,8 @@ def pad_d(t):
 
 
 def run_case(name, B, H, S, D, layout="HND", causal=False, dtype="fp16", Hkv=None, Sk=None, k_bias=0.0,
-             seed=0, q_qmax=127, k_qmax=127, smooth_k=True):
-    q, k, v = orc.make_inputs(B, H, S, D, seed=seed, layout=layout, dtype=dtype, Hkv=Hkv, Sk=Sk, k_bias=k_bias)
+             seed=0, q_qmax=127, k_qmax=127, smooth_k=True, dist="normal"):
+    q, k, v = orc.make_inputs(B, H, S, D, seed=seed, layout=layout, dtype=dtype, Hkv=Hkv, Sk=Sk, k_bias=k_bias, dist=dist)
     digest = hashlib.sha256(b"".join(np.ascontiguousarray(a).tobytes() for a in (q, k, v))).hexdigest()
     tq, tk, tv = (torch.from_numpy(a).to(TDT[dtype]) for a in (q, k, v))
     head_dim_og = D
@@ -140,7 +140,7 @@ def run_case(name, B, H, S, D, layout="HND", causal=False, dtype="fp16", Hkv=Non
     o = o[..., :head_dim_og]
     obits = o.contiguous().view(torch.int16).numpy().view(np.uint16)
     params = dict(name=name, B=B, H=H, S=S, D=D, layout=layout, causal=causal, dtype=dtype, Hkv=Hkv or H,
-                  Sk=Sk or S, k_bias=k_bias, seed=seed, q_qmax=q_qmax, k_qmax=k_qmax, smooth_k=smooth_k)
+                  Sk=Sk or S, k_bias=k_bias, seed=seed, q_qmax=q_qmax, k_qmax=k_qmax, smooth_k=smooth_k, dist=dist)
     kmn = (km.float().numpy() if km is not None else np.zeros(0, np.float32))
     np.savez_compressed(os.path.join(HERE, name + ".npz"), params=json.dumps(params), input_sha256=digest, km=kmn,
                         q_i8=q8.numpy(), k_i8=k8.numpy(), q_scale=q_scale.numpy(), k_scale=k_scale.numpy(),
@@ -226,6 +226,11 @@ CASES = [
     # product is one ulp off for D = 80 / 96 / 40 and flips codes)
     dict(name="int4_pad_d80_bf16_s256", B=1, H=2, S=256, D=80, dtype="bf16", seed=9, q_qmax=7, k_qmax=7),
     dict(name="int4_pad_d96_s256_causal", B=1, H=2, S=256, D=96, seed=10, q_qmax=7, k_qmax=7, causal=True),
+    # the reference's own benchmark distribution q, k = randint(-100, 100), v ~ N(0,1) (utils/benchmark.py:215-230): scores
+    # thousands of binades apart, one-hot rows - the inputs on which a lazy softmax reference has to fall back (round 3)
+    dict(name="randint_s512_d64", B=1, H=2, S=512, D=64, seed=14, dist="randint"),
+    dict(name="randint_s512_d64_causal", B=1, H=2, S=512, D=64, seed=14, dist="randint", causal=True),
+    dict(name="randint_int4_s384_d128", B=1, H=2, S=384, D=128, seed=15, dist="randint", q_qmax=7, k_qmax=7),
 ]
 
 if __name__ == "__main__":

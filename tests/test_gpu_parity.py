@@ -49,6 +49,19 @@ def _o_close(o, ref, dtype, atol=2e-3, rtol=2e-3):
     assert not bad.any(), f"max err {err.max():.3e} at {np.argwhere(bad)[:3].tolist()} ({bad.sum()} elements)"
 
 
+def _golden_o_close(o, ref, v, p):
+    """Kernel output against a fixture made by the reference's kernels.  N(0,1) fixtures: |dO| <= 2e-3 + 2e-3 |O| everywhere.
+    randint fixtures (scores thousands of binades wide): the same on all but <= 1 % of the ROWS - two keys in different tiles
+    whose scores tie to within the kernel's scale-grid rounding (2^-19 relative) get shifted weights; such a
+    row may move by up to 2 % of V's spread."""
+    if p.get("dist", "normal") == "normal":
+        return _o_close(o, ref, p["dtype"])
+    err = np.abs(o - ref)
+    bad_rows = (err > 2e-3 + 2e-3 * np.abs(ref)).any(axis=-1)
+    assert bad_rows.mean() <= 0.01, f"{bad_rows.sum()} of {bad_rows.size} rows differ (max err {err.max():.3e})"
+    assert err.max() <= 0.02 * (v.max() - v.min()), f"max err {err.max():.3e}"
+
+
 def _fp8_close(o, ref):
     """fp8-PV against the oracle's restatement (parity unpinned).  P is rounded to e4m3 (3 mantissa bits): a 1-ulp
     difference of exp2 at a rounding boundary flips a code (6 % of that P), which shows in rows with few keys (the first rows of
@@ -123,7 +136,7 @@ def test_attention_kernel_vs_reference_golden(oracle, dev, name):
     from lowbit_quant_fa2_paddle_amd import attn_qk_int8_per_block as attn
     p, g = load_golden(name)
     q, k, v = oracle.make_inputs(p["B"], p["H"], p["S"], p["D"], seed=p["seed"], layout=p["layout"], dtype=p["dtype"],
-                                 Hkv=p["Hkv"], Sk=p["Sk"], k_bias=p["k_bias"])
+                                 Hkv=p["Hkv"], Sk=p["Sk"], k_bias=p["k_bias"], dist=p.get("dist", "normal"))
     Dp = g["q_i8"].shape[-1]
     if Dp != p["D"]:
         v = np.pad(v, [(0, 0)] * 3 + [(0, Dp - p["D"])])
@@ -134,8 +147,9 @@ def test_attention_kernel_vs_reference_golden(oracle, dev, name):
     tv = _t(v, p["dtype"], dev)
     o, lse = attn.forward(q8, k8, tv, qs, ks, tensor_layout=p["layout"], output_dtype=TDT[p["dtype"]],
                           return_lse=True, is_causal=p["causal"])
-    _o_close(_np(o)[..., :p["D"]], g["o"], p["dtype"])
-    assert np.abs(lse.cpu().numpy() - g["lse2"]).max() <= 1e-3
+    _golden_o_close(_np(o)[..., :p["D"]], g["o"], v, p)
+    # randint fixtures: |lse2| ~ 1e4, and the kernel's per-tile scale sits on a 2^-19-relative grid
+    assert np.abs(lse.cpu().numpy() - g["lse2"]).max() <= 1e-3 + 2.0 ** -18 * np.abs(g["lse2"]).max()
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -497,14 +511,14 @@ def test_operator_end_to_end_vs_reference_golden(oracle, dev, name):
     from lowbit_quant_fa2_paddle_amd import quant_per_block as qpb
     p, g = load_golden(name)
     q, k, v = oracle.make_inputs(p["B"], p["H"], p["S"], p["D"], seed=p["seed"], layout=p["layout"], dtype=p["dtype"], Hkv=p["Hkv"],
-                                 Sk=p["Sk"], k_bias=p["k_bias"])
+                                 Sk=p["Sk"], k_bias=p["k_bias"], dist=p.get("dist", "normal"))
     tq, tk, tv = (_t(a, p["dtype"], dev) for a in (q, k, v))
     kw = dict(tensor_layout=p["layout"], is_causal=p["causal"], smooth_k=p["smooth_k"])
     if p["q_qmax"] == 127 and p["k_qmax"] == 127:
         o = lb.lowbit_fa_qk_int8_pv_fp16_triton(tq, tk, tv, **kw)
     else:
         o = lb.lowbit_fa_qk_int4_pv_fp16_triton(tq, tk, tv, q_bits=4 if p["q_qmax"] == 7 else 8, **kw)
-    _o_close(_np(o), g["o"], p["dtype"])
+    _golden_o_close(_np(o), g["o"], v, p)
     # the Q quantiser on the padded tensor, with the scale factor formed as the reference's Python does (in double)
     D = p["D"]
     Dp = 64 if D <= 64 else 128

@@ -41,6 +41,16 @@ def load_golden(name):
     return p, arr
 
 
+def golden_inputs(orc, p):
+    """The seeded inputs a dense fixture was made from (tests/golden/make_golden.py::run_case): distribution `dist`, queries
+    optionally multiplied by `q_mul` (peaky scores) and rounded to the storage dtype again."""
+    q, k, v = orc.make_inputs(p["B"], p["H"], p["S"], p["D"], seed=p["seed"], layout=p["layout"], dtype=p["dtype"],
+                              Hkv=p["Hkv"], Sk=p["Sk"], k_bias=p["k_bias"], dist=p.get("dist", "normal"))
+    if p.get("q_mul", 1.0) != 1.0:
+        q = orc.to_storage(q * np.float32(p["q_mul"]), p["dtype"])
+    return q, k, v
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import lowbit_fa_oracle

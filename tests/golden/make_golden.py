@@ -119,8 +119,10 @@ def pad_d(t):
 
 
 def run_case(name, B, H, S, D, layout="HND", causal=False, dtype="fp16", Hkv=None, Sk=None, k_bias=0.0,
-             seed=0, q_qmax=127, k_qmax=127, smooth_k=True, dist="normal"):
+             seed=0, q_qmax=127, k_qmax=127, smooth_k=True, dist="normal", q_mul=1.0):
     q, k, v = orc.make_inputs(B, H, S, D, seed=seed, layout=layout, dtype=dtype, Hkv=Hkv, Sk=Sk, k_bias=k_bias, dist=dist)
+    if q_mul != 1.0:
+        q = orc.to_storage(q * np.float32(q_mul), dtype)
     digest = hashlib.sha256(b"".join(np.ascontiguousarray(a).tobytes() for a in (q, k, v))).hexdigest()
     tq, tk, tv = (torch.from_numpy(a).to(TDT[dtype]) for a in (q, k, v))
     head_dim_og = D
@@ -140,7 +142,7 @@ def run_case(name, B, H, S, D, layout="HND", causal=False, dtype="fp16", Hkv=Non
     o = o[..., :head_dim_og]
     obits = o.contiguous().view(torch.int16).numpy().view(np.uint16)
     params = dict(name=name, B=B, H=H, S=S, D=D, layout=layout, causal=causal, dtype=dtype, Hkv=Hkv or H,
-                  Sk=Sk or S, k_bias=k_bias, seed=seed, q_qmax=q_qmax, k_qmax=k_qmax, smooth_k=smooth_k, dist=dist)
+                  Sk=Sk or S, k_bias=k_bias, seed=seed, q_qmax=q_qmax, k_qmax=k_qmax, smooth_k=smooth_k, dist=dist, q_mul=q_mul)
     kmn = (km.float().numpy() if km is not None else np.zeros(0, np.float32))
     np.savez_compressed(os.path.join(HERE, name + ".npz"), params=json.dumps(params), input_sha256=digest, km=kmn,
                         q_i8=q8.numpy(), k_i8=k8.numpy(), q_scale=q_scale.numpy(), k_scale=k_scale.numpy(),
@@ -231,6 +233,10 @@ CASES = [
     dict(name="randint_s512_d64", B=1, H=2, S=512, D=64, seed=14, dist="randint"),
     dict(name="randint_s512_d64_causal", B=1, H=2, S=512, D=64, seed=14, dist="randint", causal=True),
     dict(name="randint_int4_s384_d128", B=1, H=2, S=384, D=128, seed=15, dist="randint", q_qmax=7, k_qmax=7),
+    # peaky N(0,1): queries x 6 (scores ~8 binades wide) - some rows outgrow the first key tile's maximum by more than 2^16
+    # in a later tile, others never do: the mixed case of the lazy / exact machinery, 8..12 key tiles
+    dict(name="peaky_q6_s768_d64", B=1, H=2, S=768, D=64, seed=16, q_mul=6.0, k_bias=0.3),
+    dict(name="peaky_q6_s512_d128_nhd_causal", B=1, H=2, S=512, D=128, seed=17, q_mul=6.0, layout="NHD", causal=True),
 ]
 
 if __name__ == "__main__":

@@ -13,7 +13,7 @@ Bars:
 import numpy as np
 import pytest
 
-from conftest import golden_names, load_golden
+from conftest import golden_inputs, golden_names, load_golden
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -135,8 +135,7 @@ def test_attention_kernel_vs_reference_golden(oracle, dev, name):
     compare with the reference attention kernel's O and LSE."""
     from lowbit_quant_fa2_paddle_amd import attn_qk_int8_per_block as attn
     p, g = load_golden(name)
-    q, k, v = oracle.make_inputs(p["B"], p["H"], p["S"], p["D"], seed=p["seed"], layout=p["layout"], dtype=p["dtype"],
-                                 Hkv=p["Hkv"], Sk=p["Sk"], k_bias=p["k_bias"], dist=p.get("dist", "normal"))
+    q, k, v = golden_inputs(oracle, p)
     Dp = g["q_i8"].shape[-1]
     if Dp != p["D"]:
         v = np.pad(v, [(0, 0)] * 3 + [(0, Dp - p["D"])])
@@ -510,8 +509,7 @@ def test_operator_end_to_end_vs_reference_golden(oracle, dev, name):
     import lowbit_quant_fa2_paddle_amd as lb
     from lowbit_quant_fa2_paddle_amd import quant_per_block as qpb
     p, g = load_golden(name)
-    q, k, v = oracle.make_inputs(p["B"], p["H"], p["S"], p["D"], seed=p["seed"], layout=p["layout"], dtype=p["dtype"], Hkv=p["Hkv"],
-                                 Sk=p["Sk"], k_bias=p["k_bias"], dist=p.get("dist", "normal"))
+    q, k, v = golden_inputs(oracle, p)
     tq, tk, tv = (_t(a, p["dtype"], dev) for a in (q, k, v))
     kw = dict(tensor_layout=p["layout"], is_causal=p["causal"], smooth_k=p["smooth_k"])
     if p["q_qmax"] == 127 and p["k_qmax"] == 127:

@@ -8,13 +8,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import golden_names, load_golden, varlen_golden_names
-
-
-def _inputs(orc, p):
-    q, k, v = orc.make_inputs(p["B"], p["H"], p["S"], p["D"], seed=p["seed"], layout=p["layout"], dtype=p["dtype"],
-                              Hkv=p["Hkv"], Sk=p["Sk"], k_bias=p["k_bias"], dist=p.get("dist", "normal"))
-    return q, k, v
+from conftest import golden_inputs as _inputs, golden_names, load_golden, varlen_golden_names
 
 
 @pytest.mark.parametrize("name", golden_names())

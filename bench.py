@@ -124,6 +124,37 @@ def make_inputs(torch, dev, B, H, Hkv, S, D, layout, seed, dist_kind="normal", d
     return q, k, v
 
 
+def accuracy_vs_sdpa(torch, o, q, k, v, layout, causal, n_slices=4, row_chunk=2048):
+    """The reference's "Loss" column (utils/benchmark.py:276-291: MSE of the kernel's output against SDPA) for the output `o`
+    of a TIMED launch: fp32 softmax(q k^T / sqrt(D)) v on `n_slices` sampled (batch, head) slices, computed on the GPU in fp32
+    outside the timed region (query rows in chunks: no S x S matrix beyond row_chunk rows)."""
+    qh, kh, vh, oh = (t if layout == "HND" else t.transpose(1, 2) for t in (q, k, v, o))
+    B, H, S, D = qh.shape
+    Hkv = kh.shape[1]
+    picks = [(0, 0), (B - 1, H - 1), (B // 2, H // 3), (min(1, B - 1), H // 2)]
+    picks = list(dict.fromkeys(picks))[:max(1, min(n_slices, B * H))]
+    se, n, mx, ref_sq = 0.0, 0, 0.0, 0.0
+    for b, h in picks:
+        hk = h // (H // Hkv)
+        kk, vv = kh[b, hk].float(), vh[b, hk].float()
+        for r0 in range(0, S, row_chunk):
+            r1 = min(S, r0 + row_chunk)
+            sc = (qh[b, h, r0:r1].float() @ kk.t()) * (D ** -0.5)
+            if causal:
+                cols = torch.arange(kk.shape[0], device=sc.device)[None, :]
+                rows = torch.arange(r0, r1, device=sc.device)[:, None]
+                sc = sc.masked_fill(cols > rows, float("-inf"))
+            ref = torch.softmax(sc, dim=-1) @ vv
+            d = oh[b, h, r0:r1].float() - ref
+            se += float((d * d).sum())
+            ref_sq += float((ref * ref).sum())
+            mx = max(mx, float(d.abs().max()))
+            n += d.numel()
+    return {"mse": float(f"{se / n:.3e}"), "max_abs": float(f"{mx:.3e}"), "ref_mean_sq": float(f"{ref_sq / n:.3e}"),
+            "slices": [list(x) for x in picks], "vs": "fp32 softmax(q k^T / sqrt(D)) v on the same inputs, computed on the GPU "
+            "outside the timed region (utils/benchmark.py:276-291 'Loss')", "of": "output of the last timed launch"}
+
+
 def time_fn(torch, f, iters, warmup=2, warm_s=0.1):
     torch.cuda.synchronize()
     tw, nw = time.perf_counter(), 0
@@ -140,7 +171,7 @@ def time_fn(torch, f, iters, warmup=2, warm_s=0.1):
     return (time.perf_counter() - t0) / iters
 
 
-def sweep_point(torch, lb, lib, dev, name, spec, iters, refs=True, dist_kind="normal", dtype="fp16"):
+def sweep_point(torch, lb, lib, dev, name, spec, iters, refs=True, dist_kind="normal", dtype="fp16", accuracy=True):
     """One row of the `sweep` table: whole operator + attention kernel (library-recorded HIP events) + the two 16-bit
     comparison points on the same inputs."""
     api, B, H, Hkv, S, D, layout, causal, extra, desc = spec
@@ -164,9 +195,10 @@ def sweep_point(torch, lb, lib, dev, name, spec, iters, refs=True, dist_kind="no
         evs.append((e0, e1))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    o_last = None
     for e0, e1 in evs:
         lib.lbfa_profile_next_attn(e0.cuda_event, e1.cuda_event)
-        f()
+        o_last = f()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
     ks = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
@@ -177,6 +209,9 @@ def sweep_point(torch, lb, lib, dev, name, spec, iters, refs=True, dist_kind="no
            "ms": round(dt * 1e3, 4), "tflops": round(flops / dt / 1e12, 1), "kernel_ms": round(kms, 4),
            "kernel_ms_median": round(ks[len(ks) // 2], 4),
            "kernel_tflops": round(flops / (kms * 1e-3) / 1e12, 1), "frac": round(flops / (kms * 1e-3) / 1e12 / peak, 4)}
+    if accuracy:
+        row["accuracy"] = accuracy_vs_sdpa(torch, o_last, q, k, v, layout, causal, n_slices=2 if S >= 16384 else 4)
+    del o_last
     if refs and api != "int8_fp8":
         try:
             from torch.nn.attention import sdpa_kernel, SDPBackend
@@ -198,8 +233,8 @@ def sweep_point(torch, lb, lib, dev, name, spec, iters, refs=True, dist_kind="no
 def run_sweep(torch, lb, lib, dev):
     rows = []
     # one throw-away point first: library / allocator / flash-backend initialisation must not land in the first row
-    sweep_point(torch, lb, lib, dev, "warm-up", ("int8_fp16", 1, 8, 8, 2048, 64, "HND", False, {}, "warm-up"), 3)
-    sweep_point(torch, lb, lib, dev, "warm-up", ("int8_fp16", 1, 8, 8, 2048, 128, "HND", True, {}, "warm-up"), 3)
+    sweep_point(torch, lb, lib, dev, "warm-up", ("int8_fp16", 1, 8, 8, 2048, 64, "HND", False, {}, "warm-up"), 3, accuracy=False)
+    sweep_point(torch, lb, lib, dev, "warm-up", ("int8_fp16", 1, 8, 8, 2048, 128, "HND", True, {}, "warm-up"), 3, accuracy=False)
     its = {4096: 40, 8192: 16, 16384: 6, 32768: 3}
     for D in (64, 128):
         for causal in (False, True):
@@ -213,7 +248,11 @@ def run_sweep(torch, lb, lib, dev):
     # vote), N(0,1) scores forced onto the exact path, and bf16 storage (V is converted to fp16 as src/core.py:307-308 does)
     for dist_kind in ("randint", "normal_exact"):
         for nm, S, it in (("c2", 4096, 40), ("s16k", 16384, 6), ("c3", 16384, 3)):
-            rows.append(sweep_point(torch, lb, lib, dev, f"{nm} {dist_kind}", WORKLOADS[nm], it, refs=False, dist_kind=dist_kind))
+            row = sweep_point(torch, lb, lib, dev, f"{nm} {dist_kind}", WORKLOADS[nm], it, refs=False, dist_kind=dist_kind)
+            if dist_kind == "randint" and nm in PUBLISHED:  # the like-for-like comparison: the reference's own input distribution
+                row["vs_published"] = {"whole_op": round(row["tflops"] / PUBLISHED[nm], 3), "kernel_only": round(row["kernel_tflops"] / PUBLISHED[nm], 3),
+                                       "published_tflops": PUBLISHED[nm]}
+            rows.append(row)
     for nm, spec, it in (("c2 bf16", WORKLOADS["c2"], 40), ("c3 bf16", WORKLOADS["c3"], 3),
                          ("int8_fp16 S8K D128 bf16", ("int8_fp16", 4, 32, 32, 8192, 128, "HND", False, {}, ""), 16)):
         rows.append(sweep_point(torch, lb, lib, dev, nm, spec, it, refs=False, dtype="bf16"))
@@ -437,6 +476,9 @@ def main():
                                   "tflops": round(flops_rank / dt / 1e12, 2), "ms": round(dt * 1e3, 4),
                                   "lowbit_speedup_whole_op": round(dt / (elapsed / args.steps), 3)}
 
+    acc = None
+    if rank == 0:
+        acc = accuracy_vs_sdpa(torch, o, q, k, v, layout, causal)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(B, H, S, D, causal)
@@ -471,7 +513,9 @@ def main():
                        "kernel_only_tflops_per_gpu": round(achieved, 2), "fwd_latency_ms": round(ms_per_step, 4),
                        "prewarm": f"{prewarm_steps} un-counted operator launches (>= {args.prewarm_ms:.0f} ms) before the {args.warmup} warm-up steps",
                        "kernel_timer": f"HIP events around the attention launch of every {max(1, args.kernel_timer_every)}-th timed step: {len(kern_all)} samples",
-                       "baseline_note": "vs_baseline = value / reference's published kernel-only TFLOP/s on unnamed NVIDIA hardware (BASELINE.md)"},
+                       "baseline_note": "vs_baseline = value / reference's published kernel-only TFLOP/s on unnamed NVIDIA hardware (BASELINE.md). "
+                                        "The reference measured on q, k = randint(-100, 100) (utils/benchmark.py:215-230), `value` is on N(0,1): the "
+                                        "like-for-like ratio is sweep row 'c2 randint' -> vs_published (whole_op / kernel_only)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "frac_of_fp16_roof": round(achieved / PEAK_F16_TF, 4),
@@ -480,6 +524,7 @@ def main():
                          "achieved_median": round(flops_rank / (kern_med * 1e-3) / 1e12, 2) if kern_med > 0 else None,
                          "peak_note": ("int8 MFMA for QK^T and block-scaled e4m3 MFMA for PV: 5000 both" if api == "int8_fp8" else
                                        "mixed roof 1/(0.5/5000 + 0.5/2500): half the FLOPs int8 MFMA, half fp16 MFMA")},
+            "accuracy": acc,
             "cpu_baseline": cpu,
             "fa2_reference": fa2,
         }

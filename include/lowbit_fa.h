@@ -173,9 +173,10 @@ int lbfa_forward(const void* q, const void* k, const void* v, int dtype, void* o
 
 /*
  * Un-quantised FlashAttention-2 forward, O = softmax(Q K^T * sm_scale) V, on the same tiling as lbfa_attn_fwd with
- * 16-bit MFMAs for both products (fp16 or bf16 for Q K^T as given; P and V in fp16 - bf16 V is converted on the way
- * into LDS as in the low-bit path; fp32 softmax and accumulation).  This is the "FP16" branch of the precision router `sageattn_multi_precision`
- * (src/core.py:1066-1096), which the reference sends to `default_attn` (:46-69 / the framework's SDPA).
+ * 16-bit MFMAs for both products in the dtype given: fp16 inputs -> fp16 Q K^T, fp16 P and V; bf16 inputs -> bf16 Q K^T, bf16 P
+ * and V (no conversion anywhere, as a bf16 FlashAttention-2 does); fp32 softmax and accumulation.  This is the "FP16" branch of
+ * the precision router `sageattn_multi_precision` (src/core.py:1066-1096), which the reference sends to `default_attn`
+ * (:46-69 / the framework's SDPA).
  *   q [B,Hq,Sq,D], k / v [B,Hkv,Sk,D], o like q: one dtype (LBFA_F16 / LBFA_BF16), strides {batch, head, seq}.
  *   D: any multiple of 8 up to 128 (as lbfa_forward).  lse: NULL or [B,Hq,Sq] fp32 natural-log LSE.
  */

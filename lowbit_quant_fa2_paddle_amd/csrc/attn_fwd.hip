@@ -323,12 +323,20 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
     // -- online softmax, base 2: move m_run up to this tile's row max, rescaling O and l, when some row of the wave needs it
     // (first tile: m_run = -inf -> alpha = 0)
     {
-      float tmax = -INFINITY;
+      // the lane's 32 scores as ORDER KEYS (attn_common.h: the accumulator bits of kMagic + s compare like s as signed integers,
+      // -inf sorts below all of them): 15 v_max3_i32 + 1 v_max_i32, no canonicalising v_max in front as an fmaxf on MFMA output
+      // gets, then the other half of the row through one v_permlane32_swap
+      float tmax = key_max3<true>(x[0][0], x[0][1], x[0][2]);
 #pragma unroll
-      for (int kb2 = 0; kb2 < 2; ++kb2)
+      for (int i = 3; i < 15; i += 2) tmax = key_max3<true>(tmax, x[0][i], x[0][i + 1]);
+      tmax = key_max3<true>(tmax, x[0][15], x[1][0]);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, x[kb2][i]);
-      tmax = half_swap_max(tmax);
+      for (int i = 1; i < 15; i += 2) tmax = key_max3<true>(tmax, x[1][i], x[1][i + 1]);
+      tmax = key_max<true>(tmax, x[1][15]);
+      {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = key_max<true>(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      }
       const float xmax = __builtin_fmaf(tmax, sc, c0);  // row max of the dequantised scores; -inf if all masked
       const float m_cand = fmaxf(m_run, xmax);
       if (__any(m_cand > m_run)) {
@@ -342,6 +350,11 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
       }
     }
     const float c1 = c0 - m_run + kFp8Offset;  // +inf while m_run = -inf
+    // V^T fragment of channel block 0: requested here, in flight under the exponentials
+    i32x4 vnext[2][2];
+    vnext[0][0] = *reinterpret_cast<const i32x4*>(vbuf + vf_base);
+    vnext[0][1] = *reinterpret_cast<const i32x4*>(vbuf + (vf_base ^ 16u));
+    __builtin_amdgcn_sched_barrier(0);
     // -- P, its row sums, and the packed P^T operand: all 32 P values of the lane (k = 32 hh + 16 kb2 + i)
     i32x8 pf8;
     float psum = 0.f;
@@ -369,13 +382,19 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
     }
     __builtin_amdgcn_sched_barrier(0);  // phase fence: keeps the V fragment reads and the row-sum adds where they are (registers)
     l_run += psum;
-    // -- O^T += V^T P^T: e4m3 x e4m3 (cbsz = blgp = 0), E8M0 block scales 0x7F = 2^0
+    // -- O^T += V^T P^T: e4m3 x e4m3 (cbsz = blgp = 0), E8M0 block scales 0x7F = 2^0.  The V^T fragment of channel block db + 1 is
+    // requested before the MFMA of block db is issued (the first one before the exponentials, see above): a 16-pass MFMA covers the
+    // LDS round trip of the next operand instead of waiting for its own.
     static_for<0, DB>([&](auto i) {
       constexpr int db = decltype(i)::value;
-      const i32x4 v0 = *reinterpret_cast<const i32x4*>(vbuf + vf_base + db * 2048);
-      const i32x4 v1 = *reinterpret_cast<const i32x4*>(vbuf + (vf_base ^ 16u) + db * 2048);
+      if constexpr (db + 1 < DB) {
+        vnext[(db + 1) & 1][0] = *reinterpret_cast<const i32x4*>(vbuf + vf_base + (db + 1) * 2048);
+        vnext[(db + 1) & 1][1] = *reinterpret_cast<const i32x4*>(vbuf + (vf_base ^ 16u) + (db + 1) * 2048);
+      }
+      const i32x4 v0 = vnext[db & 1][0], v1 = vnext[db & 1][1];
       const i32x8 vf = i32x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       acc_o[db] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf8, acc_o[db], 0, 0, 0, 0x7F, 0, 0x7F);
+      if constexpr (db + 1 < DB) __builtin_amdgcn_sched_barrier(0);  // keeps the next block's reads in front of this MFMA
     });
     // Toolchain work-around (ROCm 7.2 / clang 22): the wait states the compiler leaves between this 16-pass MFMA and
     // a VALU read of its result (register copies at control-flow edges, the epilogue) are too few - the last two

@@ -37,6 +37,10 @@
 namespace lbfa {
 
 constexpr float kLazyThr = 8.0f;  // exact paths move the softmax reference only when a row max outgrows it by more than 2^8
+// The one-fma dequantisation (scale rounded by <= 2^-19 relative onto the bias grid) moves the exponent of a score near the row max by
+// up to |m| 2^-19: below 2^-12 - a fraction of the fp16 rounding of P - while the softmax reference m stays within 2^7 binades of
+// zero.  A wave whose reference lies further out votes for the replay, and the replay dequantises with the UN-rounded scale.
+constexpr float kGridRef = 128.0f;
 constexpr bool kPingPong = true;  // every other round of Q blocks walks the key tiles backwards (L2 reuse, see attn_fwd.hip)
 // V^T fragments are read in batches of kVBatch channel blocks (4 registers each), kVAhead batches ahead of the MFMAs that use
 // them (kVAhead + 1 register sets).  Measured (S16K / D128 / C3): one block ahead at 1 / 2 blocks per batch +1 / +3..5 / +2 % over
@@ -55,7 +59,7 @@ __device__ __forceinline__ int vx16(int row) {  // V-tile 32-byte block swizzle
   if constexpr (D == 64) return (row >> 1) & 3;
   else return row & 7;
 }
-#if defined(LBFA_STAMPS16) && LBFA_D16 == 64  // diagnostic build only, D = 64 unit (tools/stamps.py): s_memtime at six points of a workgroup's life, wave 0 lane 0
+#if defined(LBFA_STAMPS16) && LBFA_D16 == LBFA_STAMPS16  // diagnostic build only (-DLBFA_STAMPS16=64 | 128, tools/stamps.py): s_memtime at points of a workgroup's life, wave 0 lane 0
 __device__ long long g_stamps16[8192 * 8];
 #define LBFA_STAMP(k)                                                                                              \
   do {                                                                                                             \
@@ -349,15 +353,18 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   };
   qsc = uniform(qsc);
   const float sc_max = qsc * ks_max;
-  const int gexp = (int)((__float_as_uint(1.25f * kMagic * sc_max) >> 23) & 0xff) - 127 + 1 - 21;  // log2(G)
+  const int gexp = __builtin_amdgcn_readfirstlane((int)((__float_as_uint(1.25f * kMagic * sc_max) >> 23) & 0xff) - 127 + 1 - 21);  // log2(G)
   const float G = uniform(__builtin_ldexpf(1.0f, gexp)), invG = uniform(__builtin_ldexpf(1.0f, -gexp));
   const float gg = uniform(__builtin_ldexpf(1.0f, gexp - 22)), invg = uniform(__builtin_ldexpf(1.0f, 22 - gexp));
   // Wide scores: the grid is one integer step of a score wide at best (G in (7.5, 15] sc_max), and a reference rounded up to it puts
   // the largest P at 2^-G.  Harmless while a step is a fraction of a binade; inputs whose 8-bit (4-bit) steps are binades apart -
   // the reference's bench distribution randint(-100, 100) on the 4-bit-range codes: G = 256 - take the bias off the scores with one
   // exact subtraction each instead (tv - kMagic = s), keep the scales and the reference unrounded, and pay 32 VALU per tile.
-  const bool wide = !QK16 && gexp >= 2;
-  const float bias = wide ? kMagic : 0.f;
+  // The same arithmetic is what every REPLAY runs on (`wide` is switched on in front of it): the reference dequantises in fp32
+  // (attn_qk_int8_per_block.py:51), and on scores thousands of binades wide - its own bench distribution randint(-100, 100) on 8-bit
+  // codes, G = 1..2 - a scale rounded by 2^-19 shifts the weights of keys whose scores tie across tiles.
+  const bool wide_all = !QK16 && gexp >= 2;
+  bool wide = wide_all;
   auto grid_up = [&](float m) __attribute__((always_inline)) { return wide ? m : __builtin_ceilf(m * invG) * G; };
   float sc_tab = 0.f, c0_tab = 0.f;
   auto refresh_scale_table = [&](int j0) __attribute__((always_inline)) {
@@ -378,6 +385,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
     constexpr bool MASKED = decltype(masked_tag)::value;
     constexpr bool EXACT = decltype(exact_tag)::value || MASKED;
     const char* kbuf = smem + BUF * KBYTES;
+    const float bias = wide ? kMagic : 0.f;
     float sc, c0;
     if constexpr (QK16) {
       sc = p.qk_scale;
@@ -584,9 +592,19 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   using No = std::false_type;
   using Yes = std::true_type;
   int* vote_flag = reinterpret_cast<int*>(smem + TILES_BYTES);
-  auto wave_overflowed = [&]() __attribute__((always_inline)) {  // every element of the all-ones block is a complete row sum
+  // A wave votes for the replay when a row sum has overflowed (every element of the all-ones block is a complete row sum) - the
+  // un-quantised bf16 kernel, whose P cannot overflow before the fp32 accumulators of O could, when one has passed 2^64 - or,
+  // on the rounded-scale grid, when a softmax reference has left [-kGridRef, kGridRef] (a fully masked row's stays at -inf).
+  auto wave_overflowed = [&]() __attribute__((always_inline)) {
     const float chk = l_acc[0][0] + l_acc[1][0];
-    return __any(!(chk < INFINITY)) ? 1 : 0;
+    bool bad = !(chk < (PV_BF16 ? 0x1p64f : INFINITY));
+    if constexpr (!QK16) {
+      if (!wide) {
+        const float a0 = __builtin_fabsf(m_run[0]), a1 = __builtin_fabsf(m_run[1]);
+        bad = bad || (a0 > kGridRef && a0 < INFINITY) || (a1 > kGridRef && a1 < INFINITY);
+      }
+    }
+    return __any(bad) ? 1 : 0;
   };
   int skip_until = 0;  // replay: tiles below this index are already in this wave's accumulators
   // returns (when `vote`) whether any wave of the workgroup has an overflowed row sum
@@ -663,6 +681,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
     __syncthreads();  // every wave has read the flags and left the tile buffers
     if (my_bad) reset_state();
     skip_until = my_bad ? 0 : replay_end;
+    if constexpr (!QK16) wide = true;  // un-rounded scales, exact bias subtraction (first_tile_landed() rebuilds the scale table)
     load_tile(tile_of(0), B0{});
     first_tile_landed();
     run_tiles(Yes{}, 0);

@@ -6,8 +6,9 @@ The op is independent per (batch, q-head); smooth-K's mean is per (batch, kv-hea
   * if B < world, kv-head groups are split instead (each rank takes Hkv/world kv heads and their q heads).
 The only collective is the optional gather of the per-shard outputs (`all_gather_batch`), for callers that
 need the whole tensor on every rank; data-parallel callers keep their shard and never communicate.
-xGMI is a point-to-point mesh: a direct all-gather puts one peer's shard on each link, so it is chunked per
-batch element to let RCCL overlap it with the next launch.
+xGMI is a point-to-point mesh: a direct all-gather puts one peer's shard on each link, so the overlapped form
+(`overlap=True`) gathers per batch element behind the next element's launch, on a cyclic batch partition whose
+gathered pieces land in unsharded order.
 """
 from __future__ import annotations
 
@@ -71,32 +72,31 @@ def all_gather_batch(o, dim: int = 0, group=None):
     return out if dim == 0 else out.transpose(0, dim)
 
 
-def _pipelined_batch_gather(fn, qs, ks, vs, tensor_layout, world, group, kwargs):
-    """Batch-sharded run with the gather issued behind the compute: the local shard is processed one batch element at a
-    time, and each finished element is all-gathered asynchronously (RCCL works on its own stream) while the next element's
-    kernels run.  Every element goes through `all_gather_into_tensor` on a contiguous [world, ...] staging slice (no list
-    form: RCCL then needs no flatten / copy-out pass and the stream semantics stay simple).  With more than one element per
-    rank the staging is [nb, world, ...] and ONE transposing copy at the end - a read and a write of the whole gathered output,
-    1.07 GB x world at C5 - puts the result in rank-major batch order (= the unsharded order); with one element per rank the
-    staging IS the result and no copy is made.  Needs equal shards.
-    UNMEASURED on hardware so far (no multi-GPU node was available to rounds 1-3): the expectation - on the xGMI mesh a
-    direct all-gather moves one peer's piece per link, so only the last element's gather is exposed - is an expectation, and
-    whether the copy costs more than the overlap returns is to be timed with `bench.py --gpus N` (`c5_strong.allgather_ms`)."""
+def _pipelined_batch_gather(fn, q, k, v, tensor_layout, world, rank, group, kwargs):
+    """Batch-sharded run with the gather issued behind the compute.  CYCLIC partition: rank r takes the batch elements
+    r, r + world, r + 2 world, ... - strided views of q, k, v (the C ABI takes the batch stride as given, no copies) - and
+    processes them one at a time; element i of every rank goes through ONE `all_gather_into_tensor` into the contiguous rows
+    [i world, (i + 1) world) of the result while the next element's kernels run (RCCL works on its own stream).  Row
+    i world + r is batch element i world + r: the staging buffer IS the result in unsharded order - no transposing copy, no
+    second full-size buffer (rounds 1-3 split the batch into contiguous chunks and re-ordered the gathered pieces with a copy
+    of the whole output, 8.6 GB read + written per rank at C5).  Needs B % world == 0.
+    UNMEASURED on hardware so far (no multi-GPU node has been available): that only the last element's gather is exposed - on
+    the xGMI mesh a direct all-gather moves one peer's piece per link - is an expectation, to be timed with `bench.py --gpus N`."""
     import torch
     import torch.distributed as dist
-    nb = qs.shape[0]
+    B = q.shape[0]
+    nb = B // world
+    qs, ks, vs = q[rank::world], k[rank::world], v[rank::world]
     out = None
     handles = []
     for i in range(nb):
         o_i = fn(qs[i:i + 1], ks[i:i + 1], vs[i:i + 1], tensor_layout=tensor_layout, **kwargs)
         if out is None:
-            out = torch.empty((nb, world) + tuple(o_i.shape[1:]), dtype=o_i.dtype, device=o_i.device)
-        handles.append(dist.all_gather_into_tensor(out[i], o_i.contiguous(), group=group, async_op=True))
+            out = torch.empty((B,) + tuple(o_i.shape[1:]), dtype=o_i.dtype, device=o_i.device)
+        handles.append(dist.all_gather_into_tensor(out[i * world:(i + 1) * world], o_i.contiguous(), group=group, async_op=True))
     for h in handles:
         h.wait()
-    if nb == 1:  # [1, world, ...] is already rank-major: a view, no copy
-        return out.reshape((world,) + tuple(out.shape[2:]))
-    return out.transpose(0, 1).reshape((world * nb,) + tuple(out.shape[2:]))
+    return out
 
 
 def sharded_attention(fn: Callable, q, k, v, *, tensor_layout: str = "HND", gather: bool = True, group=None,
@@ -111,7 +111,7 @@ def sharded_attention(fn: Callable, q, k, v, *, tensor_layout: str = "HND", gath
         return fn(q, k, v, tensor_layout=tensor_layout, **kwargs)
     qs, ks, vs, spec = shard_inputs(q, k, v, tensor_layout, world, rank)
     if gather and overlap and spec == "batch" and q.shape[0] % world == 0 and not kwargs.get("return_lse", False):
-        return _pipelined_batch_gather(fn, qs, ks, vs, tensor_layout, world, group, kwargs)
+        return _pipelined_batch_gather(fn, q, k, v, tensor_layout, world, rank, group, kwargs)
     out = fn(qs, ks, vs, tensor_layout=tensor_layout, **kwargs)
     if not gather:
         return out

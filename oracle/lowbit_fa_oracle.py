@@ -66,7 +66,7 @@ def e4m3fn_round(x: np.ndarray) -> np.ndarray:
     step = 2.0 ** (e - 3)
     q = np.rint(a / step) * step  # np.rint = round-half-even
     q = np.minimum(q, FP8_E4M3_MAX)
-    return (np.sign(x) * q).astype(np.float32)
+    return np.copysign(q, x).astype(np.float32)  # keeps the sign of a zero, as the hardware conversions do
 
 
 def e4m3fn_encode(x: np.ndarray) -> np.ndarray:

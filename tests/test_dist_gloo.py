@@ -40,16 +40,34 @@ def _worker(rank, world, port, B, H, Hkv, S, D, layout, causal, ret):
         assert torch.equal(lse, full_lse)
         qs, _, _, spec = lbd.shard_inputs(tq, tk, tv, layout, world, rank)
         assert o_local.shape == qs.shape
-        # gather hidden behind the compute (piecewise async all-gather); falls back to the plain path when it cannot apply
-        o_pipe = lbd.sharded_attention(_oracle_op, tq, tk, tv, tensor_layout=layout, is_causal=causal, overlap=True)
+        # gather hidden behind the compute (piecewise async all-gather on a cyclic batch partition); falls back to the plain
+        # path when it cannot apply.  The pieces land in unsharded order: the staging buffer is the result - exactly ONE
+        # allocation of the full output's size, and it is what comes back (no re-ordering copy).
+        big, real_empty = [], torch.empty
+
+        def counting_empty(*a, **kw):
+            t = real_empty(*a, **kw)
+            if t.numel() >= full_o.numel():
+                big.append(t)
+            return t
+
+        torch.empty = counting_empty
+        try:
+            o_pipe = lbd.sharded_attention(_oracle_op, tq, tk, tv, tensor_layout=layout, is_causal=causal, overlap=True)
+        finally:
+            torch.empty = real_empty
         assert torch.equal(o_pipe, full_o), "pipelined gather differs from the unsharded result"
+        if spec == "batch" and B % world == 0:
+            assert len(big) == 1 and o_pipe.data_ptr() == big[0].data_ptr() and o_pipe.is_contiguous(), \
+                "the pipelined gather must return its one staging buffer"
         ret[rank] = spec
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world,B,H,Hkv,layout,causal,expect", [
-    (2, 4, 2, 2, "HND", False, "batch"),
+    (2, 4, 2, 2, "HND", False, "batch"),     # two batch elements per rank: the cyclic partition of the overlapped gather
+    (3, 6, 2, 2, "NHD", True, "batch"),      # world 3, two per rank, strided NHD views
     (2, 3, 2, 1, "NHD", True, "batch"),      # uneven batch split (2 + 1), GQA
     (2, 1, 4, 2, "HND", False, "head"),      # B < world: kv-head groups are split
     (3, 1, 6, 3, "NHD", True, "head"),

@@ -50,16 +50,10 @@ def _o_close(o, ref, dtype, atol=2e-3, rtol=2e-3):
 
 
 def _golden_o_close(o, ref, v, p):
-    """Kernel output against a fixture made by the reference's kernels.  N(0,1) fixtures: |dO| <= 2e-3 + 2e-3 |O| everywhere.
-    randint fixtures (scores thousands of binades wide): the same on all but <= 1 % of the ROWS - two keys in different tiles
-    whose scores tie to within the kernel's scale-grid rounding (2^-19 relative) get shifted weights; such a
-    row may move by up to 2 % of V's spread."""
-    if p.get("dist", "normal") == "normal":
-        return _o_close(o, ref, p["dtype"])
-    err = np.abs(o - ref)
-    bad_rows = (err > 2e-3 + 2e-3 * np.abs(ref)).any(axis=-1)
-    assert bad_rows.mean() <= 0.01, f"{bad_rows.sum()} of {bad_rows.size} rows differ (max err {err.max():.3e})"
-    assert err.max() <= 0.02 * (v.max() - v.min()), f"max err {err.max():.3e}"
+    """Kernel output against a fixture made by the reference's kernels: |dO| <= 2e-3 + 2e-3 |O| on EVERY element, the N(0,1)
+    fixtures and the randint / peaky ones alike (round 4: a Q block that leaves the lazy pass dequantises with the un-rounded
+    q_scale * k_scale, attn_fwd16.hip `wide`, as attn_qk_int8_per_block.py:51 does)."""
+    return _o_close(o, ref, p["dtype"])
 
 
 def _fp8_close(o, ref):

@@ -41,18 +41,6 @@ def _o_close(o, ref, atol=2e-3, rtol=2e-3):
     assert not bad.any(), f"max err {err.max():.3e} at {np.argwhere(bad)[:3].tolist()} ({bad.sum()} elements)"
 
 
-def _o_close_but_ties(o, ref, v, frac=0.01):
-    """As _o_close on all but a small fraction of ROWS.  With scores thousands of binades wide (randint inputs) the kernel's
-    per-tile dequantisation scale, rounded onto a 2^-19-relative grid so that the bias folds exactly into one fma (DESIGN 3.1
-    item 3), moves a score by up to ~0.03 binades - three orders below the int8 quantisation noise of the same score, but enough
-    to shift the weights of two keys in DIFFERENT tiles whose scores tie to within that: such a row may differ from the
-    reference by up to 2 % of the spread of V."""
-    err = np.abs(o - ref)
-    bad_rows = (err > 2e-3 + 2e-3 * np.abs(ref)).any(axis=-1)
-    assert bad_rows.mean() <= frac, f"{bad_rows.sum()} of {bad_rows.size} rows differ (max err {err.max():.3e})"
-    assert err.max() <= 0.02 * (v.max() - v.min()), f"max err {err.max():.3e}"
-
-
 def _shifted_inputs(oracle, S, D, first_high_tile, rows, spike, seed=21):
     """N(0,1) inputs whose channel 0 carries a step: keys of tiles >= first_high_tile score 2 a^2 sm_scale log2(e) ~ 23 (36
     for `spike`) binades above the earlier ones for the chosen query rows; `spike`: only that one tile is high."""
@@ -117,12 +105,12 @@ def test_reference_bench_distribution_randint(oracle, dev, D, causal):
     o, lse = lb.lowbit_fa_qk_int8_pv_fp16_triton(tq, tk, tv, is_causal=causal, return_lse=True)
     assert torch.isfinite(o).all() and torch.isfinite(lse).all()
     o_ref, lse_ref = oracle.lowbit_fa_forward(q, k, v, is_causal=causal, return_lse=True, amax_floor=1e-7, tail="neg_inf")
-    _o_close_but_ties(_np(o), o_ref, v)
+    _o_close(_np(o), o_ref)
     # |lse| ~ 1e4 here: the tolerance scales with it (fp32 ulp of the value, and of q . km rounded to fp16 - src/core.py:294-304)
     assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 1e-3 + 2.0 ** -10 * np.abs(lse_ref).max()
     o4 = lb.lowbit_fa_qk_int4_pv_fp16_triton(tq, tk, tv, is_causal=causal)
     o4_ref = oracle.lowbit_fa_forward(q, k, v, is_causal=causal, q_qmax=7, k_qmax=7, amax_floor=1e-7, tail="neg_inf")
-    _o_close_but_ties(_np(o4), o4_ref, v)
+    _o_close(_np(o4), o4_ref)
     of = core.flash_attn_fp16(tq, tk, tv, is_causal=causal)
     ref = oracle.sdpa_naive(q.astype(np.float64), k.astype(np.float64), v.astype(np.float64), is_causal=causal)
     _o_close(_np(of), ref)
@@ -193,12 +181,7 @@ def test_fuzz_peaky_inputs(oracle, dev, seed):
     qm = dict(q_qmax=7, k_qmax=7) if int4 else {}
     o_ref, lse_ref = oracle.lowbit_fa_forward(q, k, v, dtype=dt, tensor_layout=layout, is_causal=causal, return_lse=True,
                                               amax_floor=1e-7, tail="neg_inf", **qm)
-    got = _np(o)
-    if dt == "bf16":  # one bf16 ulp of the output on top
-        err = np.abs(got - o_ref)
-        assert (err <= 2e-3 + (2e-3 + 2.0 ** -7) * np.abs(o_ref)).mean() >= 0.99 and err.max() <= 0.02 * (v.max() - v.min()) + 2.0 ** -7 * np.abs(o_ref).max()
-    else:
-        _o_close_but_ties(got, o_ref, v)
+    _o_close(_np(o), o_ref, rtol=2e-3 + (2.0 ** -7 if dt == "bf16" else 0.0))  # bf16: one ulp of the output on top
     # |lse| can reach 1e4 (randint): fp32 ulps of the value and of q . km rounded to the storage dtype (src/core.py:294-304)
     ulp = 2.0 ** -10 if dt == "fp16" else 2.0 ** -7
     assert np.abs(_np(lse) - lse_ref).max() <= 1e-3 + ulp * np.abs(lse_ref).max()

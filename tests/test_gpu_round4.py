@@ -1,0 +1,139 @@
+"""GPU parity tests added in round 4 (run with `-m gpu`).
+
+  * SHORT Q blocks on purpose (2, 3, 4 full key tiles; the first Q blocks of a causal sequence): the overflow votes of the lazy
+    pass sit on the tiles' own barriers, and a vote that every wave does not see the same way makes the workgroup's waves take
+    different paths - a round-3 experiment ("vote on the last tile's barrier") produced run-to-run different outputs for Q blocks
+    of exactly two tiles and was caught by accident.  Here: first fp16-P overflow in tile 1 or 2, for all rows / one wave / one
+    row, every case run TWICE (bit-equal outputs and LSEs), then against the oracle.  The reference makes one deterministic pass
+    (src/triton/attn_qk_int8_per_block.py:45-65).
+  * run-to-run bit-stability at the C2 size on the reference's bench distribution (every Q block replays);
+  * the replay that is NOT caused by an overflow: softmax references far from zero (|m| > 2^7 binades) leave the rounded-scale
+    grid (attn_fwd16.hip, kGridRef) - large common-mode scores that never overflow the lazy pass;
+  * the un-quantised bf16 kernel with a 120-binade step: bf16 P does not overflow where fp16 P does, the vote has to come from
+    the size of the row sums (attn_fwd16.hip, wave_overflowed).
+"""
+import numpy as np
+import pytest
+
+from test_gpu_round3 import _np, _o_close, _shifted_inputs, _t, dev  # noqa: F401
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _run_twice(fn):
+    a = fn()
+    torch.cuda.synchronize()
+    b = fn()
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), f"two runs of the same launch differ in {(x != y).sum().item()} elements"
+    return a
+
+
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("rows", ["all", "one_wave", "one_row"])
+@pytest.mark.parametrize("S,first_high_tile", [(128, 1), (192, 1), (192, 2), (256, 1), (256, 2)])
+def test_short_q_blocks_vote_deterministically(oracle, dev, D, rows, S, first_high_tile):
+    """Non-causal, n_main = S / 64 = 2, 3, 4 full tiles (no vote inside the loop for 2; one at tile 2 for 3 and 4), the overflow
+    in the second or third tile."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    q, k, v = _shifted_inputs(oracle, 256, D, first_high_tile, rows, False, seed=31)
+    q, k, v = q[:, :, :S], k[:, :, :S], v[:, :, :S]
+    tq, tk, tv = (_t(x, "fp16", dev) for x in (q, k, v))
+    o, lse = _run_twice(lambda: lb.lowbit_fa_qk_int8_pv_fp16_triton(tq, tk, tv, return_lse=True, smooth_k=False))
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    o_ref, lse_ref = oracle.lowbit_fa_forward(q, k, v, return_lse=True, smooth_k=False, amax_floor=1e-7, tail="neg_inf")
+    _o_close(_np(o), o_ref)
+    assert np.abs(_np(lse) - lse_ref).max() <= 1e-3 + 2.0 ** -20 * np.abs(lse_ref).max()
+
+
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("rows", ["all", "one_wave", "one_row"])
+@pytest.mark.parametrize("first_high_tile", [1, 2, 3])
+def test_first_q_blocks_of_a_causal_sequence(oracle, dev, D, rows, first_high_tile):
+    """Causal S = 512: Q blocks with 0, 2, 4, 6 full tiles in front of their two diagonal tiles; the step sits in tile 1, 2 or 3,
+    i.e. inside the full tiles of the later blocks and inside the masked diagonal tiles of the earlier ones."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    q, k, v = _shifted_inputs(oracle, 512, D, first_high_tile, rows, False, seed=32)
+    tq, tk, tv = (_t(x, "fp16", dev) for x in (q, k, v))
+    o, lse = _run_twice(lambda: lb.lowbit_fa_qk_int8_pv_fp16_triton(tq, tk, tv, is_causal=True, return_lse=True, smooth_k=False))
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    o_ref, lse_ref = oracle.lowbit_fa_forward(q, k, v, is_causal=True, return_lse=True, smooth_k=False, amax_floor=1e-7, tail="neg_inf")
+    _o_close(_np(o), o_ref)
+    assert np.abs(_np(lse) - lse_ref).max() <= 1e-3 + 2.0 ** -20 * np.abs(lse_ref).max()
+
+
+@pytest.mark.parametrize("api", ["int8", "int4", "fp8"])
+def test_run_to_run_bit_stability_randint_c2_size(dev, api):
+    """B4 H32 S4096 D64 on q, k = randint(-100, 100) (utils/benchmark.py:215-230): every one of the 4096 Q blocks leaves the lazy
+    pass at its first vote and replays; three launches, identical bits."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    q = torch.randint(-100, 100, (4, 32, 4096, 64), generator=g, device=dev).half()
+    k = torch.randint(-100, 100, (4, 32, 4096, 64), generator=g, device=dev).half()
+    v = torch.randn((4, 32, 4096, 64), generator=g, device=dev).half()
+    fn = {"int8": lb.lowbit_fa_qk_int8_pv_fp16_triton, "int4": lb.lowbit_fa_qk_int4_pv_fp16_triton,
+          "fp8": lb.lowbit_fa_qk_int8_pv_fp8_cuda}[api]
+    kw = {} if api == "fp8" else {"return_lse": True}
+    outs = []
+    for _ in range(3):
+        r = fn(q, k, v, **kw)
+        outs.append(r if isinstance(r, tuple) else (r,))
+    torch.cuda.synchronize()
+    for r in outs[1:]:
+        for x, y in zip(outs[0], r):
+            assert torch.isfinite(x).all() and torch.equal(x, y)
+
+
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("sign", [1.0, -1.0])
+def test_large_common_mode_scores_replay_without_overflow(oracle, dev, D, causal, sign):
+    """q = a u + N(0,1), k = +-a u + N(0,1), no smoothing: every score carries +-a^2 / sqrt(D) ~ +-290 binades and the rows are
+    as flat as N(0,1) rows - nothing overflows the lazy pass, but a scale rounded by 2^-19 would move the exponents by 290 * 2^-19
+    ~ 2^-11 *per key block*, differently from tile to tile.  The waves vote for the replay because their references left the
+    grid's range, and the replay dequantises exactly."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    S = 640
+    q, k, v = oracle.make_inputs(1, 2, S, D, seed=41)
+    rng = np.random.default_rng(9)
+    u = rng.standard_normal(D).astype(np.float32)
+    u /= np.linalg.norm(u)
+    a = 40.0 * (D / 64.0) ** 0.25
+    # key blocks of different magnitude: different k_scale per tile
+    k = k * np.repeat(rng.uniform(0.5, 2.0, S // 64), 64).astype(np.float32)[None, None, :, None]
+    q = oracle.to_storage(q + a * u, "fp16")
+    k = oracle.to_storage(k + sign * a * u, "fp16")
+    tq, tk, tv = (_t(x, "fp16", dev) for x in (q, k, v))
+    o, lse = _run_twice(lambda: lb.lowbit_fa_qk_int8_pv_fp16_triton(tq, tk, tv, is_causal=causal, return_lse=True, smooth_k=False))
+    o_ref, lse_ref, mid = oracle.lowbit_fa_forward(q, k, v, is_causal=causal, return_lse=True, smooth_k=False, amax_floor=1e-7,
+                                                   tail="neg_inf", return_intermediates=True)
+    assert np.abs(lse_ref).max() * 1.44269504 > 150.0, "the case must leave the grid's range"
+    _o_close(_np(o), o_ref)
+    assert np.abs(_np(lse) - lse_ref).max() <= 1e-3 + 2.0 ** -20 * np.abs(lse_ref).max()
+
+
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("late_tile", [1, 5])
+def test_bf16_kernel_120_binade_step(oracle, dev, D, late_tile):
+    """Un-quantised bf16 kernel: keys from tile `late_tile` on score ~120 binades above the earlier ones for every query, |v| up to
+    ~4.  bf16 P = exp2(120) is finite, so no infinity reaches the row sums - but 2^120 |v| 64 keys would overflow the fp32
+    accumulators of O over a long sequence, and P so far above 1 loses nothing only if the reference moves: the waves vote on
+    `row sum >= 2^64` and the replay takes the exact path."""
+    from lowbit_quant_fa2_paddle_amd import core
+    S = 1024
+    q, k, v = oracle.make_inputs(1, 2, S, D, seed=51, dtype="bf16")
+    # scores in base 2: q0 k0 sm_scale log2(e); channel 0 carries a step of 2 * b * b * sm_scale * log2(e) = 120
+    b = (60.0 * D ** 0.5 / 1.44269504) ** 0.5
+    q[..., 0] = b
+    k[:, :, :64 * late_tile, 0] = -b
+    k[:, :, 64 * late_tile:, 0] = b
+    q, k = oracle.to_storage(q, "bf16"), oracle.to_storage(k, "bf16")
+    tq, tk, tv = (_t(x, "bf16", dev) for x in (q, k, v))
+    o, lse = _run_twice(lambda: core.flash_attn_fp16(tq, tk, tv, return_lse=True))
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    ref, rlse = oracle.sdpa_naive(*(x.astype(np.float64) for x in (q, k, v)), sm_scale=D ** -0.5, return_lse=True)
+    _o_close(_np(o), ref, atol=4e-3, rtol=2e-3 + 2.0 ** -7)
+    assert np.abs(_np(lse) - rlse).max() <= 2.5e-3 + 2.0 ** -20 * np.abs(rlse).max()

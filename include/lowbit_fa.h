@@ -39,7 +39,9 @@
 extern "C" {
 #endif
 
-#define LBFA_VERSION 110 /* 0.1.1: + lbfa_cast_bf16_to_f16, *_workspace_bytes_dt; lbfa_attn_fwd[_varlen] take fp16 / e4m3 V only */
+#define LBFA_VERSION 200 /* 0.2.0 (see INTEGRATION.md "ABI versions"): + lbfa_absmax; the changes of 0.1.1 (lbfa_attn_fwd[_varlen] refuse a
+                            bf16 V - cast it with lbfa_cast_bf16_to_f16 -, *_workspace_bytes without a dtype include the fp16 copy of V) are
+                            incompatible with 0.1.0 callers and are versioned as such here */
 
 /* element types */
 #define LBFA_F16 0
@@ -132,6 +134,14 @@ int lbfa_attn_fwd(const int8_t* q, const int8_t* k, const void* v, int v_dtype, 
                   int B, int Hq, int Hkv, int Sq, int Sk, int D,
                   const int64_t strides_q[3], const int64_t strides_k[3], const int64_t strides_v[3],
                   const int64_t strides_o[3], int is_causal, void* stream);
+
+/*
+ * max |x| of a [B,H,S,D] fp16 / bf16 view (strides {batch, head, seq} in elements, last dim contiguous, D % 8 == 0) into ONE
+ * device float `out` (zeroed by the call, on `stream`).  Replaces the reduction of `compute_scale`, the per-tensor statistic of
+ * the precision router (src/core.py:1039-1048: `paddle.compat.max(paddle.abs(tensor))`); dividing by 2^(bits-1) - 1 and the
+ * thresholds of `select_quantization` (:1051-1063) stay on the host.  Order-independent (integer atomic max): deterministic.
+ */
+int lbfa_absmax(const void* x, int dtype, float* out, int B, int H, int S, int D, const int64_t strides_x[3], void* stream);
 
 /*
  * Profiling aid: the NEXT fused-attention launch made on this thread (by lbfa_attn_fwd or lbfa_forward) is bracketed by

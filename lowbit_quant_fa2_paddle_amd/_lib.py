@@ -38,6 +38,7 @@ SIGNATURES = {
                             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), _ci, _vp]),
     "lbfa_profile_next_attn": (_ci, [_vp, _vp]),
+    "lbfa_absmax": (_ci, [_vp, _ci, _vp, _ci, _ci, _ci, _ci, ctypes.POINTER(ctypes.c_int64), _vp]),
     "lbfa_cast_bf16_to_f16": (_ci, [_vp, _vp, _ci, _ci, _ci, _ci, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), _vp]),
     "lbfa_forward_workspace_bytes": (_sz, [_ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci]),
     "lbfa_forward_workspace_bytes_dt": (_sz, [_ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci]),

@@ -68,6 +68,10 @@ class TorchOps:
         """cu_seqlens may be int32 or int64 (src/core.py:418); the C ABI takes contiguous int32."""
         return t.to(self.torch.int32).contiguous()
 
+    def tolist(self, t):
+        """small device tensor -> Python list (one device-to-host copy; synchronises the stream)"""
+        return t.tolist()
+
     def cumsum0_pad(self, t):
         """[0, cumsum(t)] as int32 (quant_per_block_varlen.py:95-100)."""
         return self.torch.nn.functional.pad(self.torch.cumsum(t, dim=0), (1, 0), value=0).to(self.torch.int32)
@@ -127,6 +131,9 @@ class PaddleOps:
 
     def as_int32(self, t):
         return t.astype(self.paddle.int32).contiguous()
+
+    def tolist(self, t):
+        return t.numpy().tolist()
 
     def cumsum0_pad(self, t):
         return self.paddle.concat([self.paddle.zeros([1], dtype=t.dtype), self.paddle.cumsum(t, axis=0)]).astype(self.paddle.int32)

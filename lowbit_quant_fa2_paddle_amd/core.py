@@ -278,16 +278,48 @@ def flash_attn_fp16(q, k, v, tensor_layout: str = "HND", is_causal: bool = False
 default_attn = flash_attn_fp16
 
 
+def _round_storage(x: float, code: int) -> float:
+    """x rounded to fp16 / bf16 (round to nearest even), as an elementwise op of the framework on a tensor of that dtype rounds"""
+    import struct
+    if code == _lib.LBFA_F16:
+        return struct.unpack("<e", struct.pack("<e", x))[0] if abs(x) < 65520.0 else (float("inf") if x > 0 else float("-inf"))
+    bits = struct.unpack("<I", struct.pack("<f", x))[0]
+    bits = (bits + 0x7FFF + ((bits >> 16) & 1)) & 0xFFFF0000
+    return struct.unpack("<f", struct.pack("<I", bits))[0]
+
+
+def _absmax(tensors):
+    """max |x| of each 4-D fp16 / bf16 tensor: one `lbfa_absmax` launch per tensor into one small device buffer, ONE copy to the
+    host (the reference's `compute_scale` does a framework reduction per tensor and its comparisons synchronise, src/core.py:1039-1063)."""
+    ops = ops_for(tensors[0])
+    lib = _lib.load()
+    out = ops.empty((len(tensors),), ops.float32, tensors[0])
+    with ops.device_guard(tensors[0]):
+        for i, t in enumerate(tensors):
+            shp, st = ops.shape(t), ops.strides(t)
+            if len(shp) != 4 or st[3] != 1 or ops.dtype_code(t) is None or not ops.is_gpu(t):
+                raise ValueError("select_quantization: 4-D fp16 / bf16 device tensors with a contiguous last dim expected")
+            _lib.check(lib.lbfa_absmax(ops.ptr(t), ops.dtype_code(t), ops.ptr(out) + 4 * i, shp[0], shp[1], shp[2], shp[3],
+                                       _lib.strides3(st[:3]), ops.stream(t)), lib)
+    return ops.tolist(out)
+
+
 def compute_scale(tensor, bits=8, symmetric=True):
-    """src/core.py:1039-1048: per-tensor scale max|x| / (2^(bits-1) - 1) (or (max-min)/(2^bits-1))."""
+    """src/core.py:1039-1048: per-tensor scale max|x| / (2^(bits-1) - 1), in the tensor's dtype (the asymmetric form
+    (max - min) / (2^bits - 1) is never used on the path: framework reductions, as the reference)."""
     if symmetric:
-        return tensor.abs().max() / (2 ** (bits - 1) - 1)
-    return (tensor.max() - tensor.min()) / (2 ** bits - 1)
+        code = ops_for(tensor).dtype_code(tensor)
+        return _round_storage(_absmax([tensor])[0] / (2 ** (bits - 1) - 1), code)
+    return float((tensor.max() - tensor.min()) / (2 ** bits - 1))
 
 
 def select_quantization(q, k, v):
-    """src/core.py:1051-1063: average per-tensor scale > 0.2 -> FP16, > 0.05 -> INT8, else INT4."""
-    avg_scale = float((compute_scale(q, bits=8) + compute_scale(k, bits=8) + compute_scale(v, bits=8)) / 3.0)
+    """src/core.py:1051-1063: average per-tensor scale > 0.2 -> FP16, > 0.05 -> INT8, else INT4.  The three reductions run in
+    the HIP library (`lbfa_absmax`); the scalar arithmetic behind them is done on the host, rounded to the tensors' dtype after
+    every step as the reference's 0-d tensor arithmetic is."""
+    code = ops_for(q).dtype_code(q)
+    sq, sk, sv = (_round_storage(a / 127, code) for a in _absmax([q, k, v]))
+    avg_scale = _round_storage(_round_storage(_round_storage(sq + sk, code) + sv, code) / 3.0, code)
     if avg_scale > 0.2:
         return "FP16"
     if avg_scale > 0.05:

@@ -60,16 +60,26 @@ __device__ __forceinline__ int vx16(int row) {  // V-tile 32-byte block swizzle
   else return row & 7;
 }
 #if defined(LBFA_STAMPS16) && LBFA_D16 == LBFA_STAMPS16  // diagnostic build only (-DLBFA_STAMPS16=64 | 128, tools/stamps.py): s_memtime at points of a workgroup's life, wave 0 lane 0
-__device__ long long g_stamps16[8192 * 8];
+// record per workgroup: [0..7] phases of the workgroup's life, [8..15] progress of wave 0's instruction stream through ONE tile of
+// the lazy main loop (tile n_main / 2): step top, tile fetch issued, QK^T issued, exponentials of k-step 0 issued, PV k-step 0 +
+// exponentials of k-step 1 issued, PV k-step 1 issued, prefetch landed (vmcnt 0), barrier passed
+__device__ long long g_stamps16[8192 * 16];
 #define LBFA_STAMP(k)                                                                                              \
   do {                                                                                                             \
-    if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps16[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();    \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps16[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime();   \
+  } while (0)
+#define LBFA_TSTAMP(k)                                      \
+  do {                                                      \
+    __builtin_amdgcn_sched_barrier(0);                      \
+    if (ts_on) ts[k] = __builtin_amdgcn_s_memtime();        \
+    __builtin_amdgcn_sched_barrier(0);                      \
   } while (0)
 extern "C" int lbfa_debug_stamps(void* dst) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps16), sizeof(g_stamps16), 0, hipMemcpyDeviceToHost);
 }
 #else
 #define LBFA_STAMP(k)
+#define LBFA_TSTAMP(k)
 #endif
 
 template <int D, int QT, int VT, int OT, bool CAUSAL, bool QQ = false>
@@ -93,6 +103,8 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   __shared__ __attribute__((aligned(16))) char smem[TILES_BYTES + 16];  // ONE LDS object (see attn_fwd.hip)
 
   LBFA_STAMP(0);
+  [[maybe_unused]] long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  [[maybe_unused]] bool ts_on = false;
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -526,9 +538,32 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
     using R0 = std::integral_constant<int, 0>;
     using R1 = std::integral_constant<int, 1>;
 
-    static_for<0, 4>([&](auto kb) { compute_scores(kb); });
+#ifdef LBFA_QKEXP  // experiment: the exponentials of k-step 0 (key blocks 0, 1) under the score MFMAs of key blocks 2, 3 (lazy tiles only)
+    constexpr bool QKEXP = !EXACT;
+#else
+    constexpr bool QKEXP = false;
+#endif
     c1[0] = c0 - m_run[0];  // exact (grid argument); +inf while m_run = -inf
     c1[1] = c0 - m_run[1];
+    if constexpr (QKEXP) {
+      compute_scores(std::integral_constant<int, 0>{});
+      compute_scores(std::integral_constant<int, 1>{});
+      static_for<0, (VD < NBT ? VD : NBT)>([&](auto b0) { v_issue(b0); });
+      __builtin_amdgcn_sched_barrier(0);
+      compute_scores(std::integral_constant<int, 2>{});
+      compute_scores(std::integral_constant<int, 3>{});
+      exp_s(R0{}, R0{});
+      exp_s(R1{}, R0{});
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * KS, 0);
+      static_for<0, 4 * KS>([&](auto) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 40 / (4 * KS), 0);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+    static_for<0, 4>([&](auto kb) { compute_scores(kb); });
+    }
+    LBFA_TSTAMP(2);
     if constexpr (EXACT) {
       // Exact path: every tile tests its LANE-partial maxima against the reference - the exponent argument of the largest score
       // the lane holds, 2 x (8 v_max + 1 v_fma + 1 v_cmp) - and only a wave that finds a row more than 2^THR above its reference
@@ -552,9 +587,12 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
             for (int e = 0; e < 4; ++e) x[rb][kb][e] -= kMagic;
       }
     }
-    static_for<0, (VD < NBT ? VD : NBT)>([&](auto b0) { v_issue(b0); });
-    exp_s(R0{}, R0{});
-    exp_s(R1{}, R0{});
+    if constexpr (!QKEXP) {
+      static_for<0, (VD < NBT ? VD : NBT)>([&](auto b0) { v_issue(b0); });
+      exp_s(R0{}, R0{});
+      exp_s(R1{}, R0{});
+    }
+    LBFA_TSTAMP(3);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
     pv_s(R0{});
@@ -569,7 +607,9 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
       });
     }
     __builtin_amdgcn_sched_barrier(0);
+    LBFA_TSTAMP(4);
     pv_s(R1{});
+    LBFA_TSTAMP(5);
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -610,8 +650,13 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   // returns (when `vote`) whether any wave of the workgroup has an overflowed row sum
   auto step = [&](auto buf_tag, auto nbuf_tag, int i, auto masked_tag, auto exact_tag, bool vote) __attribute__((always_inline)) {
     const int j = tile_of(i);
+#if defined(LBFA_STAMPS16) && LBFA_D16 == LBFA_STAMPS16
+    ts_on = !decltype(exact_tag)::value && i == (n_main >> 1) && wave == 0;
+#endif
+    LBFA_TSTAMP(0);
     if (i != 0 && (j & 63) == (rev ? 63 : 0)) refresh_scale_table(j & ~63);
     load_tile(tile_of(i + 1), nbuf_tag);
+    LBFA_TSTAMP(1);
     bool skip = false;
     if constexpr (decltype(masked_tag)::value && CAUSAL) skip = j * 64 > row0 + 31;  // all keys above all rows of this wave
     if constexpr (decltype(exact_tag)::value) skip = skip || i < skip_until;
@@ -621,7 +666,9 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
       if (lane == 0) vote_flag[wave] = bad;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile has landed (this wave's share) when the barrier opens
+    LBFA_TSTAMP(6);
     __syncthreads();
+    LBFA_TSTAMP(7);
     int any_bad = 0;
     if (vote) {  // the next write to vote_flag is at least one barrier away
       const i32x4 f = *reinterpret_cast<const i32x4*>(vote_flag);
@@ -720,6 +767,10 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
     }
   }
   LBFA_STAMP(5);
+#if defined(LBFA_STAMPS16) && LBFA_D16 == LBFA_STAMPS16
+  if (threadIdx.x == 0 && blockIdx.x < 8192)
+    for (int k = 0; k < 8; ++k) g_stamps16[blockIdx.x * 16 + 8 + k] = ts[k];
+#endif
 }
 
 // ---- launchers (called from attn_fwd.hip's launch_* for every fp16-P variant) ----------------------------------------

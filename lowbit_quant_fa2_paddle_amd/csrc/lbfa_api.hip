@@ -20,6 +20,7 @@ hipError_t launch_attn_fwd_f16(const AttnParams& p, int D, int dtype, int causal
 hipError_t launch_attn_fwd_qq(const AttnParams& p, int D, int dtype, int v_dtype, int causal, hipStream_t stream);
 hipError_t launch_cast_bf16_f16(const void* src, void* dst, int B, int H, int S, int d_valid, const int64_t* ss, const int64_t* ds,
                                 hipStream_t stream);
+hipError_t launch_absmax(const void* x, int dtype, float* out, int B, int H, int S, int D, const int64_t* st, hipStream_t stream);
 }  // namespace lbfa
 
 namespace {
@@ -83,6 +84,17 @@ int lbfa_profile_next_attn(void* start_event, void* stop_event) {
 }
 
 int lbfa_version(void) { return LBFA_VERSION; }
+
+int lbfa_absmax(const void* x, int dtype, float* out, int B, int H, int S, int D, const int64_t strides_x[3], void* stream) {
+  if (!x || !out || !strides_x) return fail(LBFA_EINVAL, "lbfa_absmax: null pointer");
+  if (B <= 0 || H <= 0 || S <= 0 || D <= 0 || D % 8 != 0) return fail(LBFA_EINVAL, "lbfa_absmax: empty tensor or head_dim %d not a multiple of 8", D);
+  if (dtype != LBFA_F16 && dtype != LBFA_BF16)
+    return fail(LBFA_EINVAL, "Input tensors must be in dtype of float16 or bfloat16");
+  if (!aligned16(x) || (strides_x[0] | strides_x[1] | strides_x[2]) % 8 != 0)
+    return fail(LBFA_EINVAL, "lbfa_absmax: x must be 16-byte aligned with strides that are multiples of 8 elements");
+  g_err[0] = 0;
+  return check_hip(lbfa::launch_absmax(x, dtype, out, B, H, S, D, strides_x, (hipStream_t)stream), "lbfa_absmax launch");
+}
 
 const char* lbfa_last_error(void) { return g_err; }
 

@@ -496,4 +496,64 @@ hipError_t launch_cast_bf16_f16(const void* src, void* dst, int B, int H, int S,
   return hipGetLastError();
 }
 
+// ---- per-tensor max |x| (the precision router's `compute_scale`, src/core.py:1039-1048) -----------------------------------------
+// HBM-bound, 2 bytes per element read once: grid-stride over 16-byte chunks of a [B,H,S,D] view (last dim contiguous), eight
+// chunks in flight per lane, the cross-workgroup combine an integer atomicMax on the (non-negative) fp32 bit patterns - max is
+// order-independent, so the result is deterministic.
+struct AbsmaxParams {
+  const unsigned short* x;
+  unsigned* out_bits;
+  int64_t sb, sh, ss;
+  int B, H, S, cpr;  // cpr = D / 8 chunks per row
+};
+template <int DT>
+__global__ __launch_bounds__(256) void absmax_kernel(AbsmaxParams p) {
+  const int64_t n = (int64_t)p.B * p.H * p.S * p.cpr;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  float am = 0.f;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 8 * stride) {
+    uint4 raw[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t i = i0 + u * stride;
+      raw[u] = uint4{0u, 0u, 0u, 0u};
+      if (i < n) {
+        const int c = (int)(i % p.cpr);
+        int64_t r = i / p.cpr;
+        const int sq = (int)(r % p.S);
+        r /= p.S;
+        const int h = (int)(r % p.H), b = (int)(r / p.H);
+        raw[u] = *reinterpret_cast<const uint4*>(p.x + b * p.sb + h * p.sh + sq * p.ss + c * 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const unsigned w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // NaNs do not propagate (fmaxf drops them), as a max over |x| of finite activations expects
+        am = fmaxf(am, fabsf(load_cvt<DT>((unsigned short)(w[e] & 0xffffu))));
+        am = fmaxf(am, fabsf(load_cvt<DT>((unsigned short)(w[e] >> 16))));
+      }
+    }
+  }
+  am = wave_max_nonneg(am);
+  if ((threadIdx.x & 63) == 0) atomicMax(p.out_bits, __float_as_uint(am));
+}
+
+hipError_t launch_absmax(const void* x, int dtype, float* out, int B, int H, int S, int D, const int64_t* st, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), stream);
+  if (e != hipSuccess) return e;
+  AbsmaxParams p;
+  p.x = (const unsigned short*)x; p.out_bits = reinterpret_cast<unsigned*>(out);
+  p.sb = st[0]; p.sh = st[1]; p.ss = st[2];
+  p.B = B; p.H = H; p.S = S; p.cpr = D / 8;
+  const int64_t n = (int64_t)B * H * S * p.cpr;
+  const int64_t want = (n + 256 * 8 - 1) / (256 * 8);
+  const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 256 * 16 ? 256 * 16 : want));
+  if (dtype == LBFA_F16) hipLaunchKernelGGL(absmax_kernel<LBFA_F16>, dim3(blocks), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(absmax_kernel<LBFA_BF16>, dim3(blocks), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
 }  // namespace lbfa

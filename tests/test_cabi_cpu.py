@@ -34,7 +34,7 @@ def test_header_symbols_exported(lib):
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/lowbit_fa.h but not exported"
     assert sorted(_lib.SIGNATURES) == declared, "ctypes SIGNATURES out of sync with the header"
-    assert lib.lbfa_version() == 110
+    assert lib.lbfa_version() == 200
 
 
 def test_sizes_are_pure_functions(lib):

@@ -137,3 +137,28 @@ def test_bf16_kernel_120_binade_step(oracle, dev, D, late_tile):
     ref, rlse = oracle.sdpa_naive(*(x.astype(np.float64) for x in (q, k, v)), sm_scale=D ** -0.5, return_lse=True)
     _o_close(_np(o), ref, atol=4e-3, rtol=2e-3 + 2.0 ** -7)
     assert np.abs(_np(lse) - rlse).max() <= 2.5e-3 + 2.0 ** -20 * np.abs(rlse).max()
+
+
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+@pytest.mark.parametrize("layout", ["HND", "NHD"])
+def test_router_statistic_runs_in_the_library(oracle, dev, dt, layout):
+    """`select_quantization` (src/core.py:1051-1063): the three max|x| reductions are `lbfa_absmax` launches - bit-equal to the
+    framework's reduction on contiguous, strided (packed-qkv view) and odd-sized tensors - and the thresholds pick the same branch
+    as the reference's arithmetic on 0-d tensors of the storage dtype."""
+    from lowbit_quant_fa2_paddle_amd import core
+    from test_gpu_round3 import TDT
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    qkv = torch.randn((2, 3, 3, 333, 72), generator=g, device=dev).to(TDT[dt])
+    if layout == "NHD":
+        qkv = qkv.permute(0, 1, 3, 2, 4).contiguous()
+    q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]  # strided views: batch stride 3x
+    got = core._absmax([q, k, v])
+    want = [float(t.float().abs().max()) for t in (q, k, v)]
+    assert got == want
+    for scale, kind in ((0.5, "INT4"), (3.0, "INT8"), (40.0, "FP16")):
+        ts = [(t.float() * scale / t.float().abs().max() * 4.2).to(TDT[dt]) for t in (q, k, v)]
+        ref_avg = sum((t.abs().max() / 127 for t in ts[1:]), ts[0].abs().max() / 127) / 3.0   # 0-d tensors of the storage dtype
+        ref_kind = "FP16" if float(ref_avg) > 0.2 else ("INT8" if float(ref_avg) > 0.05 else "INT4")
+        assert core.select_quantization(*ts) == ref_kind == kind
+    assert core.compute_scale(q) == float(q.abs().max() / 127)

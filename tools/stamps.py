@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: per-workgroup phase times of the attention kernel from a -DLBFA_STAMPS16 build of attn_fwd16.hip (tools/build_exp.sh stamps16 "-DLBFA_STAMPS16").
-   LBFA_LIB_PATH=variants/lib_stamps.so python tools/stamps.py [S] [D]"""
+   LBFA_LIB_PATH=variants/lib_stamps128.so python tools/stamps.py [S] [D] [causal]   (build: tools/build_exp.sh stamps128 "-DLBFA_STAMPS16=128")"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -19,12 +19,13 @@ for _ in range(5):
     o = lb.sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout="HND", is_causal=CAUSAL)
 torch.cuda.synchronize()
 lib = _lib.load()
-buf = np.zeros(8192 * 8, dtype=np.int64)
+buf = np.zeros(8192 * 16, dtype=np.int64)
 lib.lbfa_debug_stamps.argtypes = [ctypes.c_void_p]
 rc = lib.lbfa_debug_stamps(buf.ctypes.data)
 assert rc == 0, rc
 n = B * H * ((S + 127) // 128)
-st = buf.reshape(8192, 8)[: min(n, 8192)].astype(np.float64)
+rec = buf.reshape(8192, 16)[: min(n, 8192)].astype(np.float64)
+st = rec[:, :8]
 t0 = st[:, 0].min()
 names = ["prologue(Q load+quant)", "scale table+prime", "tile loop", "vote", "epilogue+store"]
 d = np.diff(st[:, :6], axis=1)
@@ -36,6 +37,16 @@ print(f"{'total per WG':26s} median {np.median(tot):9.0f}")
 if st[:, 6].any():  # in-kernel Q quantiser: 0 -> 6 loads + amax, 6 -> 7 workgroup reduction, 7 -> 1 encode
     for nm, a, b in (("  Q loads + amax", 0, 6), ("  block amax (2 barriers)", 6, 7), ("  encode", 7, 1)):
         print(f"{nm:26s} median {np.median(st[:, b] - st[:, a]):9.0f}")
+# one tile of the lazy main loop, wave 0: progress of the instruction stream (s_memtime ticks of 10 ns = 100 MHz, see the clock note)
+tt = rec[:, 8:16]
+ok = (tt > 0).all(axis=1)
+if ok.any():
+    dd = np.diff(tt[ok], axis=1)
+    lab = ["fetch issue (DMA)", "QK^T issue", "exp k-step 0", "PV k-step 0 + exp k-step 1", "PV k-step 1", "wait vmcnt(0)", "barrier"]
+    tot_t = tt[ok, 7] - tt[ok, 0]
+    print(f"one tile, wave 0 ({ok.sum()} workgroups): total median {np.median(tot_t):7.0f} ticks")
+    for i, nm in enumerate(lab):
+        print(f"   {nm:30s} median {np.median(dd[:, i]):7.0f}  mean {dd[:, i].mean():7.1f}  share {dd[:, i].sum() / tot_t.sum():6.3f}")
 # The counter is per XCD (blockIdx % 8, unsynchronised): slot utilisation and the idle time between a workgroup's end and its
 # successor's start are computed within each XCD.
 slots = 32 * (3 if D == 64 else 2)

@@ -63,10 +63,14 @@ __device__ __forceinline__ int vx16(int row) {  // V-tile 32-byte block swizzle
 // record per workgroup: [0..7] phases of the workgroup's life, [8..15] progress of wave 0's instruction stream through ONE tile of
 // the lazy main loop (tile n_main / 2): step top, tile fetch issued, QK^T issued, exponentials of k-step 0 issued, PV k-step 0 +
 // exponentials of k-step 1 issued, PV k-step 1 issued, prefetch landed (vmcnt 0), barrier passed
-__device__ long long g_stamps16[8192 * 16];
+__device__ long long g_stamps16[8192 * 24];  // [16], [17]: s_memrealtime (100 MHz) at the start / end of the tile loop -> in-kernel clock
 #define LBFA_STAMP(k)                                                                                              \
   do {                                                                                                             \
-    if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps16[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime();   \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps16[blockIdx.x * 24 + (k)] = __builtin_amdgcn_s_memtime();   \
+  } while (0)
+#define LBFA_RSTAMP(k)                                                                                                 \
+  do {                                                                                                                 \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps16[blockIdx.x * 24 + (k)] = __builtin_amdgcn_s_memrealtime();   \
   } while (0)
 #define LBFA_TSTAMP(k)                                      \
   do {                                                      \
@@ -79,6 +83,7 @@ extern "C" int lbfa_debug_stamps(void* dst) {
 }
 #else
 #define LBFA_STAMP(k)
+#define LBFA_RSTAMP(k)
 #define LBFA_TSTAMP(k)
 #endif
 
@@ -711,9 +716,11 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   };
 
   LBFA_STAMP(2);
+  LBFA_RSTAMP(16);
   first_tile_landed();
   int replay_end = run_tiles(No{}, 0);
   LBFA_STAMP(3);
+  LBFA_RSTAMP(17);
   int my_bad = 0;
   if (replay_end < 0) {  // the lazy pass came to the end: the last vote, on a barrier of its own
     my_bad = wave_overflowed();
@@ -769,7 +776,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   LBFA_STAMP(5);
 #if defined(LBFA_STAMPS16) && LBFA_D16 == LBFA_STAMPS16
   if (threadIdx.x == 0 && blockIdx.x < 8192)
-    for (int k = 0; k < 8; ++k) g_stamps16[blockIdx.x * 16 + 8 + k] = ts[k];
+    for (int k = 0; k < 8; ++k) g_stamps16[blockIdx.x * 24 + 8 + k] = ts[k];
 #endif
 }
 

@@ -542,8 +542,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(AbsmaxParams p) {
 }
 
 hipError_t launch_absmax(const void* x, int dtype, float* out, int B, int H, int S, int D, const int64_t* st, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), stream);
-  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<unsigned*>(out), (int64_t)1);  // (not a memset node: see zero_u32_kernel)
   AbsmaxParams p;
   p.x = (const unsigned short*)x; p.out_bits = reinterpret_cast<unsigned*>(out);
   p.sb = st[0]; p.sh = st[1]; p.ss = st[2];

@@ -118,8 +118,9 @@ def test_int8_fp8_c5_shard(oracle, dev):
     ref, lse_ref = oracle.lowbit_fa_forward(qn, kn, vn, pv="fp8", amax_floor=1e-7, return_lse=True)
     got = o[b, h, :rows].float().cpu().numpy()
     err = np.abs(got - ref[0, 0])
-    # single e4m3 codes of P may differ at rounding boundaries (see _fp8_close in test_gpu_parity.py)
-    assert np.all(err <= 0.1 + 6e-2 * np.abs(ref[0, 0])), err.max()
-    assert np.mean(err > 1e-2 + 2e-2 * np.abs(ref[0, 0])) <= 5e-3
+    # per element, as _fp8_close in test_gpu_parity.py (single e4m3 codes of P may differ at rounding boundaries: over 32768 keys
+    # they average out)
+    bad = err > 1e-2 + 2e-2 * np.abs(ref[0, 0])
+    assert not bad.any(), f"{bad.sum()} elements beyond 1e-2 + 2e-2 |ref|, max err {err.max():.3e}"
     assert float(np.mean((got - ref[0, 0]) ** 2)) <= 2e-6
     assert np.abs(lse[b, h, :rows].cpu().numpy() - lse_ref[0, 0]).max() <= 2e-3 + 2.0 ** -9 * np.abs(lse_ref).max()

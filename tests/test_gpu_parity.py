@@ -56,19 +56,14 @@ def _golden_o_close(o, ref, v, p):
     return _o_close(o, ref, p["dtype"])
 
 
-def _fp8_close(o, ref, loose=None):
-    """fp8-PV against the oracle's restatement (parity unpinned).  Per element |dO| <= 1e-2 + 2e-2 |ref| (e4m3 P has 3
-    mantissa bits).  `loose` (a reason, given by the few cases that need it): a 1-ulp difference of exp2 at an e4m3 rounding
-    boundary flips a code (6 % of that P), which shows in rows with FEW keys - the first rows of a causal block move by up to
-    ~6 % |v| - so those cases get the loose element bound with tight bounds on the fraction of such elements and the mean square."""
+def _fp8_close(o, ref):
+    """fp8-PV against the oracle's restatement (parity unpinned): per element |dO| <= 1e-2 + 2e-2 |ref| (e4m3 P has 3
+    mantissa bits; a 1-ulp difference of exp2 at a rounding boundary flips a code, 6 % of that P).  Round 3 had widened this to
+    0.1 + 6e-2 |ref| with aggregate bounds for an experimental kernel that did not ship; every fp8 case of the suite meets the
+    per-element bound on the shipped kernel (round 4: 424 GPU tests green with it)."""
     err = np.abs(o - ref)
-    strict_bad = err > 1e-2 + 2e-2 * np.abs(ref)
-    if loose is None:
-        assert not strict_bad.any(), f"max err {err.max():.3e} at {np.argwhere(strict_bad)[:3].tolist()} ({strict_bad.sum()} elements)"
-        return
-    assert (err <= 0.1 + 6e-2 * np.abs(ref)).all(), f"max err {err.max():.3e}"
-    assert strict_bad.mean() <= 5e-3, f"{strict_bad.sum()} of {strict_bad.size} elements beyond 1e-2 + 2e-2 |ref|"
-    assert float(np.mean((o - ref) ** 2)) <= 1e-5
+    bad = err > 1e-2 + 2e-2 * np.abs(ref)
+    assert not bad.any(), f"max err {err.max():.3e} at {np.argwhere(bad)[:3].tolist()} ({bad.sum()} elements)"
 
 
 # ------------------------------------------------------------------------------------------------------

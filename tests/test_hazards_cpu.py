@@ -41,11 +41,10 @@ def test_hand_issued_lds_transpose_reads_are_waited_for(attention_report):
 
 # in-loop scratch traffic the build consciously keeps (instance -> instructions inside its innermost loops); everything else: 0
 SCRATCH_ALLOWED = {
-    # causal instances at the register limit of their occupancy (168 / 256): a handful of reloads per two tiles
-    "attn_fwd16_kernelILi64ELi3ELi0ELi0ELb1ELb1E": 6,
-    "attn_fwd16_kernelILi64ELi3ELi0ELi1ELb1ELb1E": 6,
-    "attn_fwd16_kernelILi128ELi0ELi0ELi0ELb1ELb0E": 12,
-    "attn_fwd16_kernelILi128ELi1ELi1ELi1ELb1ELb0E": 12,
+    # un-quantised causal D = 128 instances at the register limit of their occupancy (256): a handful of reloads per two tiles.
+    # (Round 4: the causal int8 D = 64 instances, 6 each in round 3, are clean since the scale-grid exponent sits in an SGPR.)
+    "attn_fwd16_kernelILi128ELi0ELi0ELi0ELb1ELb0E": 8,
+    "attn_fwd16_kernelILi128ELi1ELi1ELi1ELb1ELb0E": 8,
 }
 
 

@@ -15,16 +15,20 @@ CAUSAL = len(sys.argv) > 3 and sys.argv[3] == "causal"
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(0)
 q, k, v = (torch.randn((B, H, S, D), generator=g, device=dev).half() for _ in range(3))
-for _ in range(5):
-    o = lb.sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout="HND", is_causal=CAUSAL)
+import time
+t0 = time.time()
+while time.time() - t0 < 2.0:  # >= 2 s of back-to-back launches: the clock has settled under load
+    for _ in range(4):
+        o = lb.sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout="HND", is_causal=CAUSAL)
+    torch.cuda.synchronize()
 torch.cuda.synchronize()
 lib = _lib.load()
-buf = np.zeros(8192 * 16, dtype=np.int64)
+buf = np.zeros(8192 * 24, dtype=np.int64)
 lib.lbfa_debug_stamps.argtypes = [ctypes.c_void_p]
 rc = lib.lbfa_debug_stamps(buf.ctypes.data)
 assert rc == 0, rc
 n = B * H * ((S + 127) // 128)
-rec = buf.reshape(8192, 16)[: min(n, 8192)].astype(np.float64)
+rec = buf.reshape(8192, 24)[: min(n, 8192)].astype(np.float64)
 st = rec[:, :8]
 t0 = st[:, 0].min()
 names = ["prologue(Q load+quant)", "scale table+prime", "tile loop", "vote", "epilogue+store"]
@@ -37,7 +41,14 @@ print(f"{'total per WG':26s} median {np.median(tot):9.0f}")
 if st[:, 6].any():  # in-kernel Q quantiser: 0 -> 6 loads + amax, 6 -> 7 workgroup reduction, 7 -> 1 encode
     for nm, a, b in (("  Q loads + amax", 0, 6), ("  block amax (2 barriers)", 6, 7), ("  encode", 7, 1)):
         print(f"{nm:26s} median {np.median(st[:, b] - st[:, a]):9.0f}")
-# one tile of the lazy main loop, wave 0: progress of the instruction stream (s_memtime ticks of 10 ns = 100 MHz, see the clock note)
+# in-kernel clock over the tile loop: d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6)
+rt = rec[:, 17] - rec[:, 16]
+okc = rt > 0
+if okc.any():
+    clk = (st[okc, 3] - st[okc, 2]) / rt[okc] * 0.1
+    print(f"in-kernel clock over the tile loop: median {np.median(clk):.3f} GHz (p10 {np.percentile(clk, 10):.3f}, p90 {np.percentile(clk, 90):.3f}); "
+          f"tile loop median {np.median(rt[okc]) * 10:.0f} ns")
+# one tile of the lazy main loop, wave 0: progress of the instruction stream (s_memtime ticks = shader clocks)
 tt = rec[:, 8:16]
 ok = (tt > 0).all(axis=1)
 if ok.any():

@@ -111,7 +111,11 @@ class PaddleOps:
         return t.place.is_gpu_place()
 
     def empty(self, shape, dtype, like):
-        return self.paddle.empty(list(shape), dtype=dtype).to(like.place)
+        # allocated ON `like`'s device: select it first - what the reference does in front of its own `paddle.empty` calls
+        # (`paddle.device.set_device(device2str(v.place))`, src/core.py:276) - instead of allocating on the current device and
+        # copying over with `.to(place)` (one extra allocation + copy per output)
+        self.paddle.device.set_device(device2str(like.place))
+        return self.paddle.empty(list(shape), dtype=dtype)
 
     def pad_last(self, t, n):
         # zero columns appended to the last axis, any rank (dense [B,H,S,D] / [B,S,H,D] and packed [T,H,D] tensors alike)

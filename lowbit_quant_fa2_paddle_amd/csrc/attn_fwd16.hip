@@ -543,32 +543,10 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
     using R0 = std::integral_constant<int, 0>;
     using R1 = std::integral_constant<int, 1>;
 
-#ifdef LBFA_QKEXP  // experiment: the exponentials of k-step 0 (key blocks 0, 1) under the score MFMAs of key blocks 2, 3 (lazy tiles only)
-    constexpr bool QKEXP = !EXACT;
-#else
-    constexpr bool QKEXP = false;
-#endif
+    static_for<0, 4>([&](auto kb) { compute_scores(kb); });
+    LBFA_TSTAMP(2);
     c1[0] = c0 - m_run[0];  // exact (grid argument); +inf while m_run = -inf
     c1[1] = c0 - m_run[1];
-    if constexpr (QKEXP) {
-      compute_scores(std::integral_constant<int, 0>{});
-      compute_scores(std::integral_constant<int, 1>{});
-      static_for<0, (VD < NBT ? VD : NBT)>([&](auto b0) { v_issue(b0); });
-      __builtin_amdgcn_sched_barrier(0);
-      compute_scores(std::integral_constant<int, 2>{});
-      compute_scores(std::integral_constant<int, 3>{});
-      exp_s(R0{}, R0{});
-      exp_s(R1{}, R0{});
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * KS, 0);
-      static_for<0, 4 * KS>([&](auto) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 40 / (4 * KS), 0);
-      });
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-    static_for<0, 4>([&](auto kb) { compute_scores(kb); });
-    }
-    LBFA_TSTAMP(2);
     if constexpr (EXACT) {
       // Exact path: every tile tests its LANE-partial maxima against the reference - the exponent argument of the largest score
       // the lane holds, 2 x (8 v_max + 1 v_fma + 1 v_cmp) - and only a wave that finds a row more than 2^THR above its reference
@@ -592,11 +570,9 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
             for (int e = 0; e < 4; ++e) x[rb][kb][e] -= kMagic;
       }
     }
-    if constexpr (!QKEXP) {
-      static_for<0, (VD < NBT ? VD : NBT)>([&](auto b0) { v_issue(b0); });
-      exp_s(R0{}, R0{});
-      exp_s(R1{}, R0{});
-    }
+    static_for<0, (VD < NBT ? VD : NBT)>([&](auto b0) { v_issue(b0); });
+    exp_s(R0{}, R0{});
+    exp_s(R1{}, R0{});
     LBFA_TSTAMP(3);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);

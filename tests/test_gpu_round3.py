@@ -151,7 +151,7 @@ def test_lse_of_dominant_key_rows_within_the_fp16_p_bound(oracle, dev, case, D):
     assert err.max() <= LSE_BOUND + 2.0 ** -21 * np.abs(lse_ref).max(), f"max |dLSE| {err.max():.3e}"
 
 
-N_PEAKY = 24
+N_PEAKY = int(__import__("os").environ.get("LBFA_PEAKY_N", "24"))  # one-off hunts: LBFA_PEAKY_N=300
 
 
 @pytest.mark.parametrize("seed", range(N_PEAKY))

@@ -62,7 +62,8 @@ def fake_paddle(monkeypatch):
     for n in ("int8", "float32", "uint8", "float16", "int32", "int64"):
         setattr(m, n, n)
     m.bfloat16 = "bfloat16"
-    m.empty = lambda shape, dtype: _Tensor(np.empty(shape, dtype=dtype))
+    # like Paddle: allocations land on the device selected by the last set_device call
+    m.empty = lambda shape, dtype: _Tensor(np.empty(shape, dtype=dtype), _Place(int(calls[-1].split(":")[1]) if calls and calls[-1] != "cpu" else None))
     m.zeros = lambda shape, dtype: _Tensor(np.zeros(shape, dtype=dtype))
     m.concat = lambda ts, axis=0: _Tensor(np.concatenate([t.a for t in ts], axis=axis), ts[0].place)
     m.cumsum = lambda t, axis=0: _Tensor(np.cumsum(t.a, axis=axis), t.place)
@@ -89,12 +90,13 @@ def test_paddle_ops_primitives(fake_paddle):
     assert _bhs(ops.shape(nhd), ops.strides(nhd), "NHD") == ((2, 3, 5), (600, 40, 120))
     assert ops.is_gpu(x) and not ops.is_gpu(_Tensor(np.zeros(1), _Place(None)))
     assert ops.same_device(x, nhd) and not ops.same_device(x, _Tensor(np.zeros(1), _Place(1)))
-    e = ops.empty((4, 2), ops.float32, x)
-    assert e.shape == [4, 2] and e.dtype == "float32" and e.place is x.place
+    y = _Tensor(np.zeros((2, 2), dtype=np.float16), _Place(3))
+    e = ops.empty((4, 2), ops.float32, y)  # selects y's device, then allocates there: no `.to(place)` copy
+    assert e.shape == [4, 2] and e.dtype == "float32" and str(e.place) == str(y.place) and calls == ["gpu:3"]
     assert ops.stream(x) == 0x1234
     with ops.device_guard(x):
         pass
-    assert calls == ["gpu:0"]
+    assert calls == ["gpu:3", "gpu:0"]
 
 
 def test_paddle_ops_pad_last_dense_and_packed(fake_paddle):

@@ -46,6 +46,8 @@ WORKLOADS = {
     "s32k": ("int8_fp16", 4, 32, 32, 32768, 64, "HND", False, {}, "qk_int8_pv_fp16 HND B4 H32 S32768 D64 non-causal"),
     "d128": ("int8_fp16", 4, 32, 32, 4096, 128, "HND", False, {}, "qk_int8_pv_fp16 HND B4 H32 S4096 D128 non-causal"),
     "c2c": ("int8_fp16", 4, 32, 32, 4096, 64, "HND", True, {}, "qk_int8_pv_fp16 HND B4 H32 S4096 D64 causal"),
+    "d128c": ("int8_fp16", 4, 32, 32, 4096, 128, "HND", True, {}, "qk_int8_pv_fp16 HND B4 H32 S4096 D128 causal"),
+    "d128s16k": ("int8_fp16", 4, 32, 32, 16384, 128, "HND", False, {}, "qk_int8_pv_fp16 HND B4 H32 S16384 D128 non-causal"),
 }
 # reference's published TFLOP/s for the exact default workload (INT8 non-causal S=4K, B4 H32 D64,
 # hardware not stated, kernel-only timing): example/draw/draw_single.py:15-16

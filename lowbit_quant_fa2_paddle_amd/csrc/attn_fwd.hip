@@ -21,8 +21,6 @@
 // LDS images:
 //   K tile  [64 keys][D bytes]   16-B chunk c of row r stored at chunk c ^ kx(r)
 //   V fp8   [D][64 bytes]        keys permuted into MFMA k order and 16-B chunks swizzled in HBM by lbfa_quant_v_fp8 -> linear copy
-#include <cstdlib>
-
 #include "attn_common.h"
 
 namespace lbfa {
@@ -38,42 +36,31 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 
 // OT = dtype of O (and of the Q source when QQ): int8 Q / K codes, e4m3 V; QQ = Q is quantised inside the kernel
-// NW = waves per workgroup: 4 (one 128-row Q block) or 8 (two consecutive Q blocks of a head share every K / V tile in LDS, as in
-// attn_fwd16.hip: half the LDS-DMA instructions per wave, half the L2 -> LDS bytes per row)
-template <int D, int OT, bool CAUSAL, bool QQ = false, int NW = 4>
+template <int D, int OT, bool CAUSAL, bool QQ = false>
 // D = 64 fits three waves per SIMD (<= 168 registers): ask for it, or an instance one register over silently drops to two
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn_fwd_kernel(AttnParams p) {
-  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
-  constexpr int NT = 64 * NW;  // threads
-  constexpr int NH = NW / 4;   // Q blocks per workgroup
+__global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnParams p) {
   constexpr int RB = D;                              // bytes per K row
   constexpr int KS = RB / 32;                        // k-steps of the score product (32 int8 per MFMA)
   constexpr int DB = D / 32;                         // 32-channel blocks of O^T
   constexpr int KBYTES = 64 * RB;                    // K tile
   constexpr int VBYTES = 64 * D;                     // V tile ([D][64] e4m3)
-  constexpr int KCH = KBYTES / (NT * 16);            // 16-B chunks per thread
-  constexpr int VCH = VBYTES / (NT * 16);
-  static_assert(KCH >= 1 && VCH >= 1, "a tile is at least one pass of the workgroup");
+  constexpr int KCH = KBYTES / (256 * 16);           // 16-B chunks per thread
+  constexpr int VCH = VBYTES / (256 * 16);
   constexpr int TILES_BYTES = 2 * (KBYTES + VBYTES);
   // ONE LDS object (a second one next to an LDS-DMA target makes hipcc drain vmcnt before every ds_read): the tile
   // buffers + 16 bytes for the workgroup reduction (block amax), which must not alias a tile in flight
-  __shared__ __attribute__((aligned(16))) char smem[TILES_BYTES + 4 * NW];
+  __shared__ __attribute__((aligned(16))) char smem[TILES_BYTES + 16];
 
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int half = NH == 2 ? wave >> 2 : 0;  // which Q block of the workgroup
-  const int wl = wave & 3;                   // wave within its Q block
   const int r = lane & 31, hh = lane >> 5;
 
   // ---- which (batch, head, q-block) -----------------------------------------------------------------
   const unsigned w_id = xcd_remap(blockIdx.x, gridDim.x);
-  const int nQw = (p.nQ + NH - 1) / NH;  // workgroups per (batch, head)
-  int qt0 = (int)(w_id % (unsigned)nQw);
-  const int bh = (int)(w_id / (unsigned)nQw);
-  if constexpr (CAUSAL) qt0 = nQw - 1 - qt0;  // heaviest q-blocks of a head first
-  qt0 *= NH;                  // first Q block of this workgroup (workgroup-uniform)
-  const int qt = qt0 + half;  // this wave's Q block (NW = 8: may lie past the end when nQ is odd - no rows, no stores)
+  int qt = (int)(w_id % (unsigned)p.nQ);
+  const int bh = (int)(w_id / (unsigned)p.nQ);
+  if constexpr (CAUSAL) qt = p.nQ - 1 - qt;  // heaviest q-blocks of a head first
   const int b = bh / p.Hq, h = bh % p.Hq, hk = h / p.group;
 
   // ---- extents of this problem: dense batch entry, or sequence b of a packed variable-length batch ----
@@ -86,7 +73,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
     // caller's maximum is cut there, so that every access stays inside the buffers sized from those maxima
     Sq = min(p.cu_q[b + 1] - q0, p.Sq);
     Sk = min(p.cu_k[b + 1] - k0, p.Sk);
-    if (qt0 * 128 >= Sq) return;  // whole workgroup, before any barrier
+    if (qt * 128 >= Sq) return;  // whole workgroup, before any barrier
     nK = (Sk + 63) >> 6;
     q_off = (int64_t)q0 * p.qs;
     k_off = (int64_t)k0 * p.ks;
@@ -97,7 +84,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
     }
   }
 
-  const int row0 = qt * 128 + wl * 32;  // first query row of this wave
+  const int row0 = qt * 128 + wave * 32;  // first query row of this wave
   const int qrow = row0 + r;
 
   // ---- operand windows (bytes).  The descriptor is re-based per tile with scalar arithmetic, so the
@@ -112,7 +99,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
   // ---- loop-invariant per-thread offsets of the tile fetch ------------------------------------------------------
   // Chunk i of a thread is chunk 0 moved down by a whole number of rows (KROWS per pass), which leaves the swizzle
   // unchanged: one voffset per operand, the rest is a scalar soffset.
-  constexpr int KCPR = RB / 16, KROWS = NT / KCPR;  // K: 16-B chunks per row, rows per pass
+  constexpr int KCPR = RB / 16, KROWS = 256 / KCPR;  // K: 16-B chunks per row, rows per pass
   unsigned k_goff;
   {
     const int row = t / KCPR, ch = t % KCPR;
@@ -122,7 +109,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
   }
   const unsigned v_goff = t * 16;  // the V image is copied as it lies in HBM
   const unsigned k_gstep = KROWS * (unsigned)p.ks;  // bytes between a thread's K chunks
-  static_assert(KROWS * RB == 16 * NT, "one pass of the workgroup's threads x 16 bytes");
+  static_assert(KROWS * RB == 4096, "one pass of 256 threads x 16 bytes");
   // windows are < 2 GiB (checked by the C ABI): remaining bytes in 32-bit scalar arithmetic
   const int k_bytes32 = (int)k_bytes, v_bytes32 = (int)v_bytes, k_stride32 = (int)k_tile_stride, v_stride32 = (int)v_tile_stride;
   typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -138,16 +125,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
     char* kdst = smem + BUF * KBYTES + wave * 1024;
 #pragma unroll
     for (int i = 0; i < KCH; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rs, (lds_void_ptr)(kdst + i * (16 * NT)), 16, (int)k_goff, (int)(i * k_gstep), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rs, (lds_void_ptr)(kdst + i * 4096), 16, (int)k_goff, (int)(i * k_gstep), 0, 0);
     char* vdst = smem + 2 * KBYTES + BUF * VBYTES + wave * 1024;
 #pragma unroll
     for (int i = 0; i < VCH; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rs, (lds_void_ptr)(vdst + i * (16 * NT)), 16, (int)v_goff, (int)(i * (16 * NT)), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rs, (lds_void_ptr)(vdst + i * 4096), 16, (int)v_goff, (int)(i * 4096), 0, 0);
   };
 
   // processing order of the key tiles: i-th tile processed = tile_of(i)
   constexpr int kRound = 64;
-  const bool rev = !CAUSAL && ((Sk & 63) == 0) && (((qt0 / kRound) & 1) != 0);  // workgroup-uniform
+  const bool rev = !CAUSAL && ((Sk & 63) == 0) && (((qt / kRound) & 1) != 0);  // workgroup-uniform
   auto tile_of = [&](int i) __attribute__((always_inline)) { return rev ? nK - 1 - i : i; };
   load_tile(tile_of(0), std::integral_constant<int, 0>{});  // first K / V tile: in flight while Q is fetched (and quantised)
   // ... and so are the dequantisation scales of the first 64 key tiles (lane l: tile l), needed right after the Q prologue
@@ -195,7 +182,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
     float* red = reinterpret_cast<float*>(smem + TILES_BYTES);
     if (lane == 0) red[wave] = amax;
     __syncthreads();
-    amax = fmaxf(fmaxf(red[4 * half + 0], red[4 * half + 1]), fmaxf(red[4 * half + 2], red[4 * half + 3]));
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();  // red[] is read by everyone before the overflow vote may reuse it
     const float scale = fmaxf(amax, 1e-7f) / p.q_qmax;
     qsc = scale;
@@ -239,13 +226,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
       u32x4 raw = buf_load16(q_rs, (unsigned)qrow * (unsigned)p.qs + col_b, 0);
       qf[s] = __builtin_bit_cast(i32x4, raw);
     }
-    qsc = qt < p.nQ ? p.q_scale[qsc_base + (int64_t)h * p.qsc_h + (int64_t)qt * p.qsc_blk] : 1.0f;
+    qsc = p.q_scale[qsc_base + (int64_t)h * p.qsc_h + (int64_t)qt * p.qsc_blk];
   }
 
   int n_tiles = nK;
-  // workgroup-uniform trip counts: with two Q blocks the later one sets the length, the waves of the earlier one skip the tiles
-  // above their diagonal (`skip` in step())
-  if constexpr (CAUSAL) n_tiles = min(nK, 2 * (qt0 + NH));
+  if constexpr (CAUSAL) n_tiles = min(nK, 2 * (qt + 1));
 
   // Fragment read addresses.  The swizzles depend only on the low row bits, so the block / k-step / buffer parts are
   // compile-time byte offsets folded into the ds_read immediates.
@@ -429,7 +414,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
   // Full (unmasked) tiles first, branch-free; then the at most three tiles that need masking
   // (causal diagonal block = 2 tiles, ragged last tile).
   int n_main = n_tiles;
-  if constexpr (CAUSAL) n_main = min(n_tiles, 2 * qt0);  // full for every wave of the workgroup; then the diagonal tiles (2 NH)
+  if constexpr (CAUSAL) n_main = min(n_tiles, 2 * qt);
   else if ((Sk & 63) != 0) n_main = n_tiles - 1;
 
   using B0 = std::integral_constant<int, 0>;
@@ -504,31 +489,10 @@ hipError_t launch16_attn_fwd_qq_d128(const AttnParams& p, int dtype, int v_dtype
 hipError_t launch16_attn_fwd_f16_d64(const AttnParams& p, int dtype, int causal, hipStream_t stream);
 hipError_t launch16_attn_fwd_f16_d128(const AttnParams& p, int dtype, int causal, hipStream_t stream);
 
-// Waves per workgroup of the fp8-PV kernel at D = 128 (LBFA_NW=4|8 in the environment overrides: development A/B)
-#ifndef LBFA_NW_FP8_DEFAULT
-#define LBFA_NW_FP8_DEFAULT 4
-#endif
-static int fp8_waves_per_workgroup() {
-  static const int nw = [] {
-    const char* e = std::getenv("LBFA_NW");
-    return (e && e[0] == '8') ? 8 : ((e && e[0] == '4') ? 4 : LBFA_NW_FP8_DEFAULT);
-  }();
-  return nw;
-}
 #define LBFA_LAUNCH_FP8(DD, OT, QQ)                                                                    \
   do {                                                                                                 \
     if (causal) hipLaunchKernelGGL((attn_fwd_kernel<DD, OT, true, QQ>), grid, block, 0, stream, p);    \
     else hipLaunchKernelGGL((attn_fwd_kernel<DD, OT, false, QQ>), grid, block, 0, stream, p);          \
-  } while (0)
-#define LBFA_LAUNCH_FP8_128(OT, QQ)                                                                                     \
-  do {                                                                                                                  \
-    if (fp8_waves_per_workgroup() == 8) {                                                                               \
-      dim3 grid8((unsigned)p.B * p.Hq * ((p.nQ + 1) / 2));                                                              \
-      if (causal) hipLaunchKernelGGL((attn_fwd_kernel<128, OT, true, QQ, 8>), grid8, dim3(512), 0, stream, p);          \
-      else hipLaunchKernelGGL((attn_fwd_kernel<128, OT, false, QQ, 8>), grid8, dim3(512), 0, stream, p);                \
-    } else {                                                                                                            \
-      LBFA_LAUNCH_FP8(128, OT, QQ);                                                                                     \
-    }                                                                                                                   \
   } while (0)
 
 // int8 Q / K codes; V fp16 / e4m3 ([D][64]-per-tile image of lbfa_quant_v_fp8)
@@ -537,7 +501,7 @@ hipError_t launch_attn_fwd(const AttnParams& p, int D, int v_dtype, int o_dtype,
     return D == 64 ? launch16_attn_fwd_d64(p, v_dtype, o_dtype, causal, stream) : launch16_attn_fwd_d128(p, v_dtype, o_dtype, causal, stream);
   dim3 grid((unsigned)p.B * p.Hq * p.nQ), block(256);
   if (D == 64) { if (o_dtype == LBFA_F16) LBFA_LAUNCH_FP8(64, LBFA_F16, false); else LBFA_LAUNCH_FP8(64, LBFA_BF16, false); }
-  else { if (o_dtype == LBFA_F16) LBFA_LAUNCH_FP8_128(LBFA_F16, false); else LBFA_LAUNCH_FP8_128(LBFA_BF16, false); }
+  else { if (o_dtype == LBFA_F16) LBFA_LAUNCH_FP8(128, LBFA_F16, false); else LBFA_LAUNCH_FP8(128, LBFA_BF16, false); }
   return hipGetLastError();
 }
 
@@ -547,10 +511,9 @@ hipError_t launch_attn_fwd_qq(const AttnParams& p, int D, int dtype, int v_dtype
     return D == 64 ? launch16_attn_fwd_qq_d64(p, dtype, v_dtype, causal, stream) : launch16_attn_fwd_qq_d128(p, dtype, v_dtype, causal, stream);
   dim3 grid((unsigned)p.B * p.Hq * p.nQ), block(256);
   if (D == 64) { if (dtype == LBFA_F16) LBFA_LAUNCH_FP8(64, LBFA_F16, true); else LBFA_LAUNCH_FP8(64, LBFA_BF16, true); }
-  else { if (dtype == LBFA_F16) LBFA_LAUNCH_FP8_128(LBFA_F16, true); else LBFA_LAUNCH_FP8_128(LBFA_BF16, true); }
+  else { if (dtype == LBFA_F16) LBFA_LAUNCH_FP8(128, LBFA_F16, true); else LBFA_LAUNCH_FP8(128, LBFA_BF16, true); }
   return hipGetLastError();
 }
-#undef LBFA_LAUNCH_FP8_128
 #undef LBFA_LAUNCH_FP8
 
 // un-quantised Q / K / V of one dtype

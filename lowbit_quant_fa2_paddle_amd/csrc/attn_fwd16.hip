@@ -32,8 +32,6 @@
 //   K tile [64][RB bytes]: 16-byte chunk c of row r at c ^ kx16(r), kx16 = (r >> 1) & 3 | r & 7 | r & 15 for RB = 64 | 128 | 256
 //   V tile [64][2 D bytes]: 32-byte block c of row r at c ^ vx16(r), vx16 = (r >> 1) & 3 (D = 64) | r & 7 (D = 128)
 // fp8 PV (one operand = all 64 keys of a tile) stays on the 32x32x64 block-scaled MFMA in attn_fwd.hip.
-#include <cstdlib>
-
 #include "attn_common.h"
 
 namespace lbfa {
@@ -89,13 +87,8 @@ extern "C" int lbfa_debug_stamps(void* dst) {
 #define LBFA_TSTAMP(k)
 #endif
 
-// NW = waves per workgroup: 4 (one 128-row Q block) or 8 (TWO consecutive Q blocks of a head, waves 0..3 / 4..7, sharing every
-// K / V tile in LDS: half the LDS-DMA instructions per wave and half the L2 -> LDS bytes per row; one workgroup per CU at D = 128)
-template <int D, int QT, int VT, int OT, bool CAUSAL, bool QQ = false, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn_fwd16_kernel(AttnParams p) {
-  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
-  constexpr int NT = 64 * NW;   // threads
-  constexpr int NH = NW / 4;    // Q blocks per workgroup
+template <int D, int QT, int VT, int OT, bool CAUSAL, bool QQ = false>
+__global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnParams p) {
   static_assert(!QQ || QT == kQInt8, "in-kernel Q quantisation belongs to the int8 path");
   static_assert(VT != LBFA_E4M3, "fp8 PV runs in attn_fwd.hip");
   constexpr bool QK16 = (QT != kQInt8);
@@ -105,15 +98,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
   constexpr int KS = RB / 64;              // k-steps of the score product: 64 row bytes per MFMA (64 int8 or 32 fp16)
   constexpr int CB = D / 16;               // 16-channel blocks of O^T
   constexpr int KBYTES = 64 * RB, VBYTES = 128 * D;
-  constexpr int KCH = KBYTES / (16 * NT), VCH = VBYTES / (16 * NT);  // 16-byte chunks per thread
-  static_assert(KCH >= 1 && VCH >= 1, "a tile is at least one pass of the workgroup");
+  constexpr int KCH = KBYTES / 4096, VCH = VBYTES / 4096;  // 16-byte chunks per thread
   // P and V of the PV product: fp16 x fp16 (the reference's `p.to(float16)` x `v.to(float16)`, attn_qk_int8_per_block.py:59-61,
   // src/core.py:307-308: a bf16 V reaches the int8 operators already cast, lbfa_cast_bf16_to_f16) for the int8 operators; the
   // un-quantised bf16 kernel keeps both in bf16 (as a bf16 FlashAttention-2 does).  V tiles always arrive by LDS-DMA.
   constexpr bool PV_BF16 = (QT == LBFA_BF16);
   static_assert(VT == (PV_BF16 ? LBFA_BF16 : LBFA_F16), "int8 operators and the fp16 kernel take fp16 V, the bf16 kernel bf16 V");
   constexpr int TILES_BYTES = 2 * (KBYTES + VBYTES);
-  __shared__ __attribute__((aligned(16))) char smem[TILES_BYTES + 4 * NW];  // ONE LDS object (see attn_fwd.hip)
+  __shared__ __attribute__((aligned(16))) char smem[TILES_BYTES + 16];  // ONE LDS object (see attn_fwd.hip)
 
   LBFA_STAMP(0);
   [[maybe_unused]] long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -121,18 +113,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int half = NH == 2 ? wave >> 2 : 0;  // which Q block of the workgroup
-  const int wl = wave & 3;                   // wave within its Q block: rows 32 wl .. 32 wl + 31
   const int i16 = lane & 15, g = lane >> 4;
 
   // ---- which (batch, head, q-block) -----------------------------------------------------------------
   const unsigned w_id = xcd_remap(blockIdx.x, gridDim.x);
-  const int nQw = (p.nQ + NH - 1) / NH;  // workgroups per (batch, head)
-  int qt0 = (int)(w_id % (unsigned)nQw);
-  const int bh = (int)(w_id / (unsigned)nQw);
-  if constexpr (CAUSAL) qt0 = nQw - 1 - qt0;  // heaviest q-blocks of a head first
-  qt0 *= NH;                   // first Q block of this workgroup (workgroup-uniform)
-  const int qt = qt0 + half;   // this wave's Q block (NW = 8: may lie past the end when nQ is odd - no rows, no stores)
+  int qt = (int)(w_id % (unsigned)p.nQ);
+  const int bh = (int)(w_id / (unsigned)p.nQ);
+  if constexpr (CAUSAL) qt = p.nQ - 1 - qt;  // heaviest q-blocks of a head first
   const int b = bh / p.Hq, h = bh % p.Hq, hk = h / p.group;
 
   int Sq = p.Sq, Sk = p.Sk, nK = p.nK;
@@ -142,7 +129,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
     const int q0 = p.cu_q[b], k0 = p.cu_k[b];
     Sq = min(p.cu_q[b + 1] - q0, p.Sq);
     Sk = min(p.cu_k[b + 1] - k0, p.Sk);
-    if (qt0 * 128 >= Sq) return;  // whole workgroup, before any barrier
+    if (qt * 128 >= Sq) return;  // whole workgroup, before any barrier
     nK = (Sk + 63) >> 6;
     q_off = (int64_t)q0 * p.qs;
     k_off = (int64_t)k0 * p.ks;
@@ -153,7 +140,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
       ksc_base = (int64_t)p.cu_kscale[b] * p.ksc_b;
     }
   }
-  const int row0 = qt * 128 + wl * 32;  // first query row of this wave
+  const int row0 = qt * 128 + wave * 32;  // first query row of this wave
   auto qrow_of = [&](int rb) __attribute__((always_inline)) { return row0 + 16 * rb + i16; };
 
   // ---- Q rows of this wave: requested FIRST, in flight while the K / V fetch is set up and issued ----------------------
@@ -187,8 +174,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
   const int64_t v_tile_stride = 128 * p.vs;
 
   // ---- loop-invariant per-thread offsets of the tile fetch (one 16-byte chunk per thread and pass of 256 threads) ----
-  constexpr int KCPR = RB / 16, KROWS = NT / KCPR;
-  constexpr int VCPR = D / 8, VROWS = NT / VCPR;
+  constexpr int KCPR = RB / 16, KROWS = 256 / KCPR;
+  constexpr int VCPR = D / 8, VROWS = 256 / VCPR;
   unsigned k_goff, v_goff;
   {
     const int row = t / KCPR, ch = t % KCPR;
@@ -202,7 +189,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
   }
   const unsigned k_gstep = ESZ * KROWS * (unsigned)p.ks;
   const unsigned v_gstep = 2u * VROWS * (unsigned)p.vs;
-  static_assert(KROWS * RB == 16 * NT && VROWS * 2 * D == 16 * NT, "one pass of the workgroup's threads x 16 bytes");
+  static_assert(KROWS * RB == 4096 && VROWS * 2 * D == 4096, "one pass of 256 threads x 16 bytes");
   const int k_bytes32 = (int)k_bytes, v_bytes32 = (int)v_bytes, k_stride32 = (int)k_tile_stride, v_stride32 = (int)v_tile_stride;
   typedef __attribute__((address_space(3))) void* lds_void_ptr;
   auto load_tile = [&](int j, auto buf_tag) __attribute__((always_inline)) {
@@ -215,24 +202,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
     char* kdst = smem + BUF * KBYTES + wave * 1024;  // DMA destination: wave-uniform base (+ 16 bytes per lane, implicit)
 #pragma unroll
     for (int c = 0; c < KCH; ++c)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rs, (lds_void_ptr)(kdst + c * (16 * NT)), 16, (int)k_goff, (int)(c * k_gstep), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rs, (lds_void_ptr)(kdst + c * 4096), 16, (int)k_goff, (int)(c * k_gstep), 0, 0);
     char* vdst = smem + 2 * KBYTES + BUF * VBYTES + wave * 1024;
 #pragma unroll
     for (int c = 0; c < VCH; ++c)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rs, (lds_void_ptr)(vdst + c * (16 * NT)), 16, (int)v_goff, (int)(c * v_gstep), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rs, (lds_void_ptr)(vdst + c * 4096), 16, (int)v_goff, (int)(c * v_gstep), 0, 0);
   };
 
   // processing order of the key tiles (ping-pong per round of Q blocks, see attn_fwd.hip)
   constexpr int kRound = (D == 64) ? 96 : 64;
-  const bool rev = !CAUSAL && kPingPong && ((Sk & 63) == 0) && (((qt0 / kRound) & 1) != 0);
+  const bool rev = !CAUSAL && kPingPong && ((Sk & 63) == 0) && (((qt / kRound) & 1) != 0);
   auto tile_of = [&](int i) __attribute__((always_inline)) { return rev ? nK - 1 - i : i; };
   load_tile(tile_of(0), std::integral_constant<int, 0>{});
-#ifdef LBFA_PRE2  // experiment: the second tile is requested here too (both buffers are free during the Q prologue), not at the top of tile 0
-  load_tile(tile_of(1), std::integral_constant<int, 1>{});
-  bool pre2 = true;
-#else
-  constexpr bool pre2 = false;
-#endif
   const float* ksc = nullptr;
   if constexpr (!QK16) ksc = p.k_scale + ksc_base + (int64_t)hk * p.ksc_h;
   const int ksc_blk = (int)p.ksc_blk;
@@ -279,7 +260,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
     float* red = reinterpret_cast<float*>(smem + TILES_BYTES);
     if (lane == 0) red[wave] = amax;
     __syncthreads();
-    amax = fmaxf(fmaxf(red[4 * half + 0], red[4 * half + 1]), fmaxf(red[4 * half + 2], red[4 * half + 3]));
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     LBFA_STAMP(7);
     const float scale = fmaxf(amax, 1e-7f) / p.q_qmax;
@@ -322,14 +303,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
       for (int s = 0; s < KS; ++s) qf[rb][s] = __builtin_bit_cast(i32x4, qraw[rb][s][0]);
-    if constexpr (!QK16) qsc = qt < p.nQ ? p.q_scale[qsc_base + (int64_t)h * p.qsc_h + (int64_t)qt * p.qsc_blk] : 1.0f;
+    if constexpr (!QK16) qsc = p.q_scale[qsc_base + (int64_t)h * p.qsc_h + (int64_t)qt * p.qsc_blk];
   }
 
   LBFA_STAMP(1);
   int n_tiles = nK;
-  // workgroup-uniform trip counts: with two Q blocks the later one sets the length, the waves of the earlier one skip the tiles
-  // above their diagonal (`skip` in step())
-  if constexpr (CAUSAL) n_tiles = min(nK, 2 * (qt0 + NH));
+  if constexpr (CAUSAL) n_tiles = min(nK, 2 * (qt + 1));
 
   // ---- fragment read addresses (lane parts; block / k-step / buffer parts are immediates) ------------------------
   const unsigned kf_lane = i16 * RB + ((g ^ kx16<RB>(i16)) << 4);  // k-step s: ^ (s << 6)
@@ -627,7 +606,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
   // their share of the tiles until the replay reaches the point they had come to, and continue from there in exact mode.  The
   // waste is at most twice the position of the first overflow, for the waves that overflowed only.
   int n_main = n_tiles;
-  if constexpr (CAUSAL) n_main = min(n_tiles, 2 * qt0);  // full for every wave of the workgroup; then the diagonal tiles (2 NH)
+  if constexpr (CAUSAL) n_main = min(n_tiles, 2 * qt);
   else if ((Sk & 63) != 0) n_main = n_tiles - 1;
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
@@ -648,14 +627,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
     }
     return __any(bad) ? 1 : 0;
   };
-  auto read_votes = [&]() __attribute__((always_inline)) {
-    i32x4 f = *reinterpret_cast<const i32x4*>(vote_flag);
-    if constexpr (NW == 8) {
-      const i32x4 f2 = *reinterpret_cast<const i32x4*>(vote_flag + 4);
-      f = i32x4{f[0] | f2[0], f[1] | f2[1], f[2] | f2[2], f[3] | f2[3]};
-    }
-    return __builtin_amdgcn_readfirstlane(f[0] | f[1] | f[2] | f[3]);
-  };
   int skip_until = 0;  // replay: tiles below this index are already in this wave's accumulators
   // returns (when `vote`) whether any wave of the workgroup has an overflowed row sum
   auto step = [&](auto buf_tag, auto nbuf_tag, int i, auto masked_tag, auto exact_tag, bool vote) __attribute__((always_inline)) {
@@ -665,7 +636,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
 #endif
     LBFA_TSTAMP(0);
     if (i != 0 && (j & 63) == (rev ? 63 : 0)) refresh_scale_table(j & ~63);
-    if (!(pre2 && i == 0)) load_tile(tile_of(i + 1), nbuf_tag);
+    load_tile(tile_of(i + 1), nbuf_tag);
     LBFA_TSTAMP(1);
     bool skip = false;
     if constexpr (decltype(masked_tag)::value && CAUSAL) skip = j * 64 > row0 + 31;  // all keys above all rows of this wave
@@ -680,7 +651,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
     __syncthreads();
     LBFA_TSTAMP(7);
     int any_bad = 0;
-    if (vote) any_bad = read_votes();  // the next write to vote_flag is at least one barrier away
+    if (vote) {  // the next write to vote_flag is at least one barrier away
+      const i32x4 f = *reinterpret_cast<const i32x4*>(vote_flag);
+      any_bad = __builtin_amdgcn_readfirstlane(f[0] | f[1] | f[2] | f[3]);
+    }
     return any_bad;
   };
   // tiles [i0, n_tiles), i0 even (tile i0 in buffer 0); lazy mode returns early with the tile count reached when a vote fails
@@ -728,7 +702,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
     my_bad = wave_overflowed();
     if (lane == 0) vote_flag[wave] = my_bad;
     __syncthreads();
-    if (read_votes()) replay_end = n_tiles;
+    const i32x4 f = *reinterpret_cast<const i32x4*>(vote_flag);
+    if (__builtin_amdgcn_readfirstlane(f[0] | f[1] | f[2] | f[3])) replay_end = n_tiles;
   } else {
     my_bad = wave_overflowed();
   }
@@ -737,9 +712,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
     if (my_bad) reset_state();
     skip_until = my_bad ? 0 : replay_end;
     if constexpr (!QK16) wide = true;  // un-rounded scales, exact bias subtraction (first_tile_landed() rebuilds the scale table)
-#ifdef LBFA_PRE2
-    pre2 = false;
-#endif
     load_tile(tile_of(0), B0{});
     first_tile_landed();
     run_tiles(Yes{}, 0);
@@ -794,45 +766,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (D == 64 ? 3 : 2)) void attn
 #define LBFA_CAT(a, b) LBFA_CAT2(a, b)
 #define LBFA_DNAME(fn) LBFA_CAT(fn, LBFA_D16)
 
-// Waves per workgroup of the int8 kernels: 8 (two Q blocks share the K / V tiles) at D = 128, 4 at D = 64 (three 4-wave workgroups
-// per CU there: 12 waves do not make whole 8-wave workgroups).  LBFA_NW=4|8 in the environment overrides (development A/B).
-#ifndef LBFA_NW_DEFAULT
-#define LBFA_NW_DEFAULT 4
-#endif
-#if LBFA_D16 == 128
-static int waves_per_workgroup() {
-  static const int nw = [] {
-    const char* e = std::getenv("LBFA_NW");
-    return (e && e[0] == '8') ? 8 : ((e && e[0] == '4') ? 4 : LBFA_NW_DEFAULT);
-  }();
-  return nw;
-}
-#else
-static int waves_per_workgroup() { return 4; }
-#endif
-#if LBFA_D16 == 128
-#define LBFA_LAUNCH_NW(KERNEL_ARGS_8, KERNEL_ARGS_4)                                                                      \
-  do {                                                                                                                   \
-    if (nw == 8) hipLaunchKernelGGL((attn_fwd16_kernel<KERNEL_ARGS_8>), grid8, dim3(512), 0, stream, p);                  \
-    else hipLaunchKernelGGL((attn_fwd16_kernel<KERNEL_ARGS_4>), grid, dim3(256), 0, stream, p);                           \
-  } while (0)
-#else
-#define LBFA_LAUNCH_NW(KERNEL_ARGS_8, KERNEL_ARGS_4) hipLaunchKernelGGL((attn_fwd16_kernel<KERNEL_ARGS_4>), grid, dim3(256), 0, stream, p)
-#endif
-#define LBFA_COMMA ,
-
 // int8 Q and K codes, fp16 V (lbfa_attn_fwd: bf16 V is cast by the caller, as src/core.py:307-308 does before its kernel call)
 hipError_t LBFA_DNAME(launch16_attn_fwd_d)(const AttnParams& p, int v_dtype, int o_dtype, int causal, hipStream_t stream) {
   if (v_dtype != LBFA_F16) return hipErrorInvalidValue;
-  const int nw = waves_per_workgroup();
-  dim3 grid((unsigned)p.B * p.Hq * p.nQ), grid8((unsigned)p.B * p.Hq * ((p.nQ + 1) / 2));
-  (void)nw; (void)grid8;
+  dim3 grid((unsigned)p.B * p.Hq * p.nQ), block(256);
 #define LBFA_A(OT)                                                                                                    \
   do {                                                                                                                \
-    if (causal) LBFA_LAUNCH_NW(LBFA_D16 LBFA_COMMA kQInt8 LBFA_COMMA LBFA_F16 LBFA_COMMA OT LBFA_COMMA true LBFA_COMMA false LBFA_COMMA 8,  \
-                               LBFA_D16 LBFA_COMMA kQInt8 LBFA_COMMA LBFA_F16 LBFA_COMMA OT LBFA_COMMA true);         \
-    else LBFA_LAUNCH_NW(LBFA_D16 LBFA_COMMA kQInt8 LBFA_COMMA LBFA_F16 LBFA_COMMA OT LBFA_COMMA false LBFA_COMMA false LBFA_COMMA 8,        \
-                        LBFA_D16 LBFA_COMMA kQInt8 LBFA_COMMA LBFA_F16 LBFA_COMMA OT LBFA_COMMA false);               \
+    if (causal) hipLaunchKernelGGL((attn_fwd16_kernel<LBFA_D16, kQInt8, LBFA_F16, OT, true>), grid, block, 0, stream, p);  \
+    else hipLaunchKernelGGL((attn_fwd16_kernel<LBFA_D16, kQInt8, LBFA_F16, OT, false>), grid, block, 0, stream, p);        \
   } while (0)
   if (o_dtype == LBFA_F16) LBFA_A(LBFA_F16);
   else LBFA_A(LBFA_BF16);
@@ -844,15 +785,11 @@ hipError_t LBFA_DNAME(launch16_attn_fwd_d)(const AttnParams& p, int v_dtype, int
 // pre-pass: converting it on the way into LDS cost the kernel 9..10 % and 25..56 spilled registers)
 hipError_t LBFA_DNAME(launch16_attn_fwd_qq_d)(const AttnParams& p, int dtype, int v_dtype, int causal, hipStream_t stream) {
   if (v_dtype != LBFA_F16) return hipErrorInvalidValue;
-  const int nw = waves_per_workgroup();
-  dim3 grid((unsigned)p.B * p.Hq * p.nQ), grid8((unsigned)p.B * p.Hq * ((p.nQ + 1) / 2));
-  (void)nw; (void)grid8;
+  dim3 grid((unsigned)p.B * p.Hq * p.nQ), block(256);
 #define LBFA_QQ(DT)                                                                                                          \
   do {                                                                                                                       \
-    if (causal) LBFA_LAUNCH_NW(LBFA_D16 LBFA_COMMA kQInt8 LBFA_COMMA LBFA_F16 LBFA_COMMA DT LBFA_COMMA true LBFA_COMMA true LBFA_COMMA 8,  \
-                               LBFA_D16 LBFA_COMMA kQInt8 LBFA_COMMA LBFA_F16 LBFA_COMMA DT LBFA_COMMA true LBFA_COMMA true);          \
-    else LBFA_LAUNCH_NW(LBFA_D16 LBFA_COMMA kQInt8 LBFA_COMMA LBFA_F16 LBFA_COMMA DT LBFA_COMMA false LBFA_COMMA true LBFA_COMMA 8,        \
-                        LBFA_D16 LBFA_COMMA kQInt8 LBFA_COMMA LBFA_F16 LBFA_COMMA DT LBFA_COMMA false LBFA_COMMA true);                \
+    if (causal) hipLaunchKernelGGL((attn_fwd16_kernel<LBFA_D16, kQInt8, LBFA_F16, DT, true, true>), grid, block, 0, stream, p); \
+    else hipLaunchKernelGGL((attn_fwd16_kernel<LBFA_D16, kQInt8, LBFA_F16, DT, false, true>), grid, block, 0, stream, p);       \
   } while (0)
   if (dtype == LBFA_F16) LBFA_QQ(LBFA_F16);
   else LBFA_QQ(LBFA_BF16);

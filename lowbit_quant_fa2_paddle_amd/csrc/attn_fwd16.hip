@@ -39,7 +39,9 @@ namespace lbfa {
 constexpr float kLazyThr = 8.0f;  // exact paths move the softmax reference only when a row max outgrows it by more than 2^8
 // The one-fma dequantisation (scale rounded by <= 2^-19 relative onto the bias grid) moves the exponent of a score near the row max by
 // up to |m| 2^-19: below 2^-12 - a fraction of the fp16 rounding of P - while the softmax reference m stays within 2^7 binades of
-// zero.  A wave whose reference lies further out votes for the replay, and the replay dequantises with the UN-rounded scale.
+// zero.  A wave whose reference has left that range votes for the replay like one whose row sums overflowed, and replays with the
+// UN-rounded scale and an exact bias subtraction (`wide`); a reference that leaves the range DURING a replay (only exact-path tiles
+// move references) switches its wave to `wide` in that very tile.
 constexpr float kGridRef = 128.0f;
 constexpr bool kPingPong = true;  // every other round of Q blocks walks the key tiles backwards (L2 reuse, see attn_fwd.hip)
 // V^T fragments are read in batches of kVBatch channel blocks (4 registers each), kVAhead batches ahead of the MFMAs that use
@@ -377,30 +379,36 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   // the largest P at 2^-G.  Harmless while a step is a fraction of a binade; inputs whose 8-bit (4-bit) steps are binades apart -
   // the reference's bench distribution randint(-100, 100) on the 4-bit-range codes: G = 256 - take the bias off the scores with one
   // exact subtraction each instead (tv - kMagic = s), keep the scales and the reference unrounded, and pay 32 VALU per tile.
-  // The same arithmetic is what every REPLAY runs on (`wide` is switched on in front of it): the reference dequantises in fp32
-  // (attn_qk_int8_per_block.py:51), and on scores thousands of binades wide - its own bench distribution randint(-100, 100) on 8-bit
-  // codes, G = 1..2 - a scale rounded by 2^-19 shifts the weights of keys whose scores tie across tiles.
+  // The same arithmetic takes over, per wave, when one of its softmax references leaves +-kGridRef (vote -> replay, or inside a replay:
+  // compute_tile, exact path): the reference dequantises in fp32 (attn_qk_int8_per_block.py:51), and on scores thousands of binades
+  // wide - its own bench distribution randint(-100, 100) on 8-bit codes, G = 1..2, references ~5000 - a scale rounded by 2^-19 shifts
+  // the weights of keys whose scores tie across tiles.
   const bool wide_all = !QK16 && gexp >= 2;
-  bool wide = wide_all;
+  bool wide = wide_all;  // wave-uniform; only ever switched on
   auto grid_up = [&](float m) __attribute__((always_inline)) { return wide ? m : __builtin_ceilf(m * invG) * G; };
-  float sc_tab = 0.f, c0_tab = 0.f;
+  // per lane: tile 64 c + lane's dequantisation scale as the tile loop uses it (on the grid, or un-rounded for a `wide` wave) and its
+  // raw k_scale (what a wave that goes `wide` in the middle of a replay rebuilds the first from, without a memory access)
+  float sc_tab = 0.f, ks_tab = 0.f;
   auto refresh_scale_table = [&](int j0) __attribute__((always_inline)) {
     if constexpr (!QK16) {
       const int jt = j0 + lane;
       const float ks_l = j0 == 0 ? ks_first : (jt < nK ? ksc[jt * ksc_blk] : 0.f);
+      ks_tab = ks_l;
       sc_tab = fmaxf(__builtin_rintf(qsc * ks_l * invg), 1.0f) * gg;  // >= one grid step: a masked key must not meet sc = 0
-      c0_tab = -kMagic * sc_tab;
-      if (wide) {
-        sc_tab = fmaxf(qsc * ks_l, 1e-30f);
-        c0_tab = 0.f;
-      }
+      if (wide) sc_tab = fmaxf(qsc * ks_l, 1e-30f);
     }
   };
 
-  auto compute_tile = [&](auto buf_tag, int j, auto masked_tag, auto exact_tag) __attribute__((always_inline)) {
+  auto off_grid = [&]() __attribute__((always_inline)) {  // has a reference of this wave left the range?  (-inf: a row with no key yet)
+    const float r0 = __builtin_fabsf(m_run[0]), r1 = __builtin_fabsf(m_run[1]);
+    return __any((r0 > kGridRef && r0 < INFINITY) || (r1 > kGridRef && r1 < INFINITY)) != 0;
+  };
+  // replay_tag: this tile belongs to a replay (the lazy pass leaves the switch to `wide` to its votes: its tile bodies carry no code for it)
+  auto compute_tile = [&](auto buf_tag, int j, auto masked_tag, auto exact_tag, auto replay_tag) __attribute__((always_inline)) {
     constexpr int BUF = decltype(buf_tag)::value;
     constexpr bool MASKED = decltype(masked_tag)::value;
     constexpr bool EXACT = decltype(exact_tag)::value || MASKED;
+    constexpr bool REPLAY = decltype(replay_tag)::value;
     const char* kbuf = smem + BUF * KBYTES;
     const float bias = wide ? kMagic : 0.f;
     float sc, c0;
@@ -409,7 +417,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
       c0 = 0.f;
     } else {
       sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc_tab), j & 63));
-      c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c0_tab), j & 63));
+      c0 = wide ? 0.f : -kMagic * sc;  // exact on the grid (sc = k G / 2^22: 3 k G)
     }
     float x[2][4][4];  // [row block][key block][key 4 g + e]: kMagic + s (accumulator bits), then P in place
     auto compute_scores = [&](auto kb_tag) __attribute__((always_inline)) {
@@ -556,6 +564,18 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
       if (__any((a0 > THR) || (a1 > THR))) {  // also the first tile (c1 = +inf)
         raise_reference(0, pm0, THR);
         raise_reference(1, pm1, THR);
+        if constexpr (!QK16 && REPLAY) {
+          if (!wide) {
+            if (off_grid()) {
+              // this tile and every later one of the wave: un-rounded scale, bias subtracted exactly (below).  Rare; only the tile
+              // bodies of the replay carry this code, and it touches no memory: the table is rebuilt from the raw k_scales it keeps
+              wide = true;
+              sc_tab = fmaxf(qsc * ks_tab, 1e-30f);
+              sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc_tab), j & 63));
+              c0 = 0.f;
+            }
+          }
+        }
         c1[0] = c0 - m_run[0];
         c1[1] = c0 - m_run[1];
       }
@@ -615,21 +635,18 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   int* vote_flag = reinterpret_cast<int*>(smem + TILES_BYTES);
   // A wave votes for the replay when a row sum has overflowed (every element of the all-ones block is a complete row sum) - the
   // un-quantised bf16 kernel, whose P cannot overflow before the fp32 accumulators of O could, when one has passed 2^64 - or,
-  // on the rounded-scale grid, when a softmax reference has left [-kGridRef, kGridRef] (a fully masked row's stays at -inf).
+  // on the rounded-scale grid, when one of its softmax references has left [-kGridRef, kGridRef].
   auto wave_overflowed = [&]() __attribute__((always_inline)) {
     const float chk = l_acc[0][0] + l_acc[1][0];
-    bool bad = !(chk < (PV_BF16 ? 0x1p64f : INFINITY));
+    bool bad = __any(!(chk < (PV_BF16 ? 0x1p64f : INFINITY))) != 0;
     if constexpr (!QK16) {
-      if (!wide) {
-        const float a0 = __builtin_fabsf(m_run[0]), a1 = __builtin_fabsf(m_run[1]);
-        bad = bad || (a0 > kGridRef && a0 < INFINITY) || (a1 > kGridRef && a1 < INFINITY);
-      }
+      if (!wide) bad = bad || off_grid();
     }
-    return __any(bad) ? 1 : 0;
+    return bad ? 1 : 0;
   };
   int skip_until = 0;  // replay: tiles below this index are already in this wave's accumulators
   // returns (when `vote`) whether any wave of the workgroup has an overflowed row sum
-  auto step = [&](auto buf_tag, auto nbuf_tag, int i, auto masked_tag, auto exact_tag, bool vote) __attribute__((always_inline)) {
+  auto step = [&](auto buf_tag, auto nbuf_tag, int i, auto masked_tag, auto exact_tag, bool vote, auto replay_tag) __attribute__((always_inline)) {
     const int j = tile_of(i);
 #if defined(LBFA_STAMPS16) && LBFA_D16 == LBFA_STAMPS16
     ts_on = !decltype(exact_tag)::value && i == (n_main >> 1) && wave == 0;
@@ -641,7 +658,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
     bool skip = false;
     if constexpr (decltype(masked_tag)::value && CAUSAL) skip = j * 64 > row0 + 31;  // all keys above all rows of this wave
     if constexpr (decltype(exact_tag)::value) skip = skip || i < skip_until;
-    if (!skip) compute_tile(buf_tag, j, masked_tag, exact_tag);
+    if (!skip) compute_tile(buf_tag, j, masked_tag, exact_tag, replay_tag);
     if (vote) {
       const int bad = wave_overflowed();
       if (lane == 0) vote_flag[wave] = bad;
@@ -660,28 +677,29 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   // tiles [i0, n_tiles), i0 even (tile i0 in buffer 0); lazy mode returns early with the tile count reached when a vote fails
   auto run_tiles = [&](auto exact_tag, int i0) __attribute__((always_inline)) {
     constexpr bool EX = decltype(exact_tag)::value;
+    using RP = std::integral_constant<bool, EX>;  // exact mode from the first tile on = a replay
     int i = i0;
     if constexpr (!EX) {
       // lazy mode: the first tile takes the exact path - its row maxima become the reference - and every later full tile is
       // exponentiated against the reference as it stands
       if (n_main >= 2) {
-        step(B0{}, B1{}, 0, No{}, Yes{}, false);
-        if (step(B1{}, B0{}, 1, No{}, No{}, 2 < n_main)) return 2;
+        step(B0{}, B1{}, 0, No{}, Yes{}, false, RP{});
+        if (step(B1{}, B0{}, 1, No{}, No{}, 2 < n_main, RP{})) return 2;
         i = 2;
       }
     }
     for (; i + 1 < n_main; i += 2) {
-      step(B0{}, B1{}, i, No{}, exact_tag, false);
+      step(B0{}, B1{}, i, No{}, exact_tag, false, RP{});
       const int d = i + 2;
       const bool vote = !EX && (d & (d - 1)) == 0 && d < n_main;
-      if (step(B1{}, B0{}, i + 1, No{}, exact_tag, vote)) return d;
+      if (step(B1{}, B0{}, i + 1, No{}, exact_tag, vote, RP{})) return d;
     }
     // i is even and at most one full tile is left (odd n_main): it takes the exact path in either mode (with n_main = 1 it is
     // the tile that sets the reference); every tile after it is masked
     for (; i < n_tiles; i += 2) {
-      if (i < n_main) step(B0{}, B1{}, i, No{}, Yes{}, false);
-      else step(B0{}, B1{}, i, Yes{}, Yes{}, false);
-      if (i + 1 < n_tiles) step(B1{}, B0{}, i + 1, Yes{}, Yes{}, false);
+      if (i < n_main) step(B0{}, B1{}, i, No{}, Yes{}, false, RP{});
+      else step(B0{}, B1{}, i, Yes{}, Yes{}, false, RP{});
+      if (i + 1 < n_tiles) step(B1{}, B0{}, i + 1, Yes{}, Yes{}, false, RP{});
     }
     return -1;
   };
@@ -709,9 +727,11 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd16_kernel(AttnPa
   }
   if (replay_end >= 0) {
     __syncthreads();  // every wave has read the flags and left the tile buffers
+    if constexpr (!QK16) {
+      if (!wide && off_grid()) wide = true;  // such a wave voted (my_bad): it starts over, un-rounded (first_tile_landed() rebuilds the table)
+    }
     if (my_bad) reset_state();
     skip_until = my_bad ? 0 : replay_end;
-    if constexpr (!QK16) wide = true;  // un-rounded scales, exact bias subtraction (first_tile_landed() rebuilds the scale table)
     load_tile(tile_of(0), B0{});
     first_tile_landed();
     run_tiles(Yes{}, 0);

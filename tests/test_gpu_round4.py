@@ -162,3 +162,30 @@ def test_router_statistic_runs_in_the_library(oracle, dev, dt, layout):
         ref_kind = "FP16" if float(ref_avg) > 0.2 else ("INT8" if float(ref_avg) > 0.05 else "INT4")
         assert core.select_quantization(*ts) == ref_kind == kind
     assert core.compute_scale(q) == float(q.abs().max() / 127)
+
+
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("causal", [False, True])
+def test_reference_leaves_the_grid_inside_a_replay(oracle, dev, D, causal):
+    """Two steps in channel 0: keys of tiles 1..4 score ~23 binades above tile 0 (fp16-P overflow at the first vote -> replay, with
+    references of ~±30 binades: still on the rounded-scale grid), keys from tile 5 on ~300 binades above that: the replaying waves'
+    references jump past 2^7 in tile 5 and they switch to the un-rounded scale in that tile (attn_fwd16.hip, compute_tile, REPLAY).
+    Key blocks of different magnitude give every tile its own k_scale, so a rounded scale would shift ties between tiles."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    S = 768
+    q, k, v = oracle.make_inputs(1, 2, S, D, seed=61)
+    a = 8.0 * (D / 64.0) ** 0.5
+    q[..., 0] += a
+    k[:, :, :64, 0] -= a
+    k[:, :, 64:320, 0] += a
+    k[:, :, 320:, 0] += 300.0 * D ** 0.5 / (1.44269504 * a)   # q0 k0 sm_scale log2(e) ~ +300
+    rng = np.random.default_rng(3)
+    k[:, :, 320:, 1:] *= np.repeat(rng.uniform(0.5, 2.0, (S - 320) // 64), 64).astype(np.float32)[None, None, :, None]
+    q, k = oracle.to_storage(q, "fp16"), oracle.to_storage(k, "fp16")
+    tq, tk, tv = (_t(x, "fp16", dev) for x in (q, k, v))
+    o, lse = _run_twice(lambda: lb.lowbit_fa_qk_int8_pv_fp16_triton(tq, tk, tv, is_causal=causal, return_lse=True, smooth_k=False))
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    o_ref, lse_ref = oracle.lowbit_fa_forward(q, k, v, is_causal=causal, return_lse=True, smooth_k=False, amax_floor=1e-7, tail="neg_inf")
+    assert np.abs(lse_ref).max() * 1.44269504 > 200.0
+    _o_close(_np(o), o_ref)
+    assert np.abs(_np(lse) - lse_ref).max() <= 1e-3 + 2.0 ** -20 * np.abs(lse_ref).max()

@@ -42,9 +42,13 @@ def test_hand_issued_lds_transpose_reads_are_waited_for(attention_report):
 # in-loop scratch traffic the build consciously keeps (instance -> instructions inside its innermost loops); everything else: 0
 SCRATCH_ALLOWED = {
     # un-quantised causal D = 128 instances at the register limit of their occupancy (256): a handful of reloads per two tiles.
-    # (Round 4: the causal int8 D = 64 instances, 6 each in round 3, are clean since the scale-grid exponent sits in an SGPR.)
     "attn_fwd16_kernelILi128ELi0ELi0ELi0ELb1ELb0E": 8,
     "attn_fwd16_kernelILi128ELi1ELi1ELi1ELb1ELb0E": 8,
+    # causal int8 D = 64 instances with the in-kernel Q quantiser: a few reloads (one dword pair, one dword) in the loop over the masked diagonal tiles, which runs
+    # ONCE per Q block (tools/scratch_report.py names the loop; the main tile loops, lazy and replay, are clean - round 3 carried 6
+    # reloads in them)
+    "attn_fwd16_kernelILi64ELi3ELi0ELi0ELb1ELb1E": 4,
+    "attn_fwd16_kernelILi64ELi3ELi0ELi1ELb1ELb1E": 4,
 }
 
 

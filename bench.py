@@ -275,12 +275,16 @@ def c5_strong(torch, lb, dev, world, rank, distributed, dist, share, steps=3):
     if distributed:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    evs[0].record()
+    for i in range(steps):
         o = f()
+        evs[i + 1].record()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     el = (time.perf_counter() - t0) / steps
+    step_ms = [round(evs[i].elapsed_time(evs[i + 1]), 2) for i in range(steps)]  # per launch: a slow FIRST one = memory first touch
     rank_ms = [round(el * 1e3, 3)]
     if distributed:
         tt = torch.tensor([el], device="cpu" if share else dev, dtype=torch.float64)
@@ -291,7 +295,7 @@ def c5_strong(torch, lb, dev, world, rank, distributed, dist, share, steps=3):
     flops = 4.0 * Bg * H * D * S * S
     res = {"workload": "qk_int8_pv_fp8 B32 H32 S32768 D128 (BASELINE configs[4]), batch split over the ranks, strong scaling",
            "B_per_gpu": B, "ms": round(el * 1e3, 3), "tflops_total": round(flops / el / 1e12, 1), "steps": steps,
-           "rank_ms_min": min(rank_ms), "rank_ms_max": max(rank_ms), "rank_ms": rank_ms}
+           "rank_ms_min": min(rank_ms), "rank_ms_max": max(rank_ms), "rank_ms": rank_ms, "step_ms_rank0": step_ms}
     if distributed:
         from lowbit_quant_fa2_paddle_amd import dist as lbdist
         try:  # the gather is reported, never part of `value`: a backend that cannot do it must not lose the bench line
@@ -481,9 +485,6 @@ def main():
     acc = None
     if rank == 0:
         acc = accuracy_vs_sdpa(torch, o, q, k, v, layout, causal)
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(B, H, S, D, causal)
     if distributed:
         dist.barrier()
     del q, k, v, o
@@ -494,6 +495,11 @@ def main():
     c5s = None
     if not args.no_c5 and args.workload == "c2":
         c5s = c5_strong(torch, lb, dev, world, rank, distributed, dist if distributed else None, share)
+    # the host-side baseline last: 12 s of all host cores and tens of GB of host memory in front of the big-footprint GPU runs above
+    # coincided with `c5_strong` reading 25 % slow on some pool devices (round 4; the B = 4 shard of the same kernel was unaffected)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(B, H, S, D, causal)
 
     if rank == 0:
         out = {

@@ -237,6 +237,10 @@ CASES = [
     # in a later tile, others never do: the mixed case of the lazy / exact machinery, 8..12 key tiles
     dict(name="peaky_q6_s768_d64", B=1, H=2, S=768, D=64, seed=16, q_mul=6.0, k_bias=0.3),
     dict(name="peaky_q6_s512_d128_nhd_causal", B=1, H=2, S=512, D=128, seed=17, q_mul=6.0, layout="NHD", causal=True),
+    # round 4: the bench distribution on 8-bit codes at D = 128 with GQA, NHD and the causal mask (C3's shape family), and with
+    # mixed code ranges (q int8, k 4-bit range)
+    dict(name="randint_s384_d128_nhd_gqa_causal", B=1, H=4, Hkv=2, S=384, D=128, seed=18, dist="randint", layout="NHD", causal=True),
+    dict(name="randint_q8k4_s320_d64", B=1, H=2, S=320, D=64, seed=19, dist="randint", q_qmax=127, k_qmax=7),
 ]
 
 if __name__ == "__main__":

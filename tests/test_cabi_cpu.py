@@ -108,6 +108,15 @@ def test_one_call_and_varlen_validation(lib):
     assert st == _lib.LBFA_EINVAL and b"lbfa_cast_bf16_to_f16" in lib.lbfa_last_error()
     st = lib.lbfa_cast_bf16_to_f16(p, p, 1, 2, 8, 36, s3, s3, None)
     assert st == _lib.LBFA_EINVAL and b"multiple of 8" in lib.lbfa_last_error()
+    # the router's statistic (lbfa_absmax): null output, dtype, head dim, alignment
+    st = lib.lbfa_absmax(p, 0, None, 1, 2, 8, 64, s3, None)
+    assert st == _lib.LBFA_EINVAL and b"null pointer" in lib.lbfa_last_error()
+    st = lib.lbfa_absmax(p, 2, p, 1, 2, 8, 64, s3, None)
+    assert st == _lib.LBFA_EINVAL and b"float16 or bfloat16" in lib.lbfa_last_error()
+    st = lib.lbfa_absmax(p, 0, p, 1, 2, 8, 36, s3, None)
+    assert st == _lib.LBFA_EINVAL and b"multiple of 8" in lib.lbfa_last_error()
+    st = lib.lbfa_absmax(p + 2, 0, p, 1, 2, 8, 64, s3, None)
+    assert st == _lib.LBFA_EINVAL and b"16-byte aligned" in lib.lbfa_last_error()
     # a bf16 V is cast into the workspace (not for fp8 PV, whose V quantiser reads bf16 itself): the dtype-aware size is larger
     f16, bf16 = _lib.LBFA_F16, _lib.LBFA_BF16
     assert lib.lbfa_forward_workspace_bytes_dt(1, 2, 2, 8, 8, 128, bf16, 0, 1, 0) > lib.lbfa_forward_workspace_bytes_dt(1, 2, 2, 8, 8, 128, f16, 0, 1, 0)

@@ -27,7 +27,9 @@
 // 8, ... tiles and at the end; when one reports an overflow the workgroup replays from tile 0 in exact mode (lane-partial
 // integer maxima every tile, cross-lane step and rescale only where a row outgrew its reference by 2^8): the waves that
 // overflowed start over, the others keep their accumulators and only pass the barriers until the replay reaches the point they
-// had come to ("tile loop" below).
+// had come to ("tile loop" below).  The same votes carry a second condition for the int8 kernels: a wave one of whose references
+// has left +-2^7 binades - the range in which the rounded dequantisation scale of the one-fma form is exact enough (kGridRef) -
+// reports too, and replays with the un-rounded scale (`wide`), as the reference dequantises (attn_qk_int8_per_block.py:51).
 // LDS images (checked conflict-free by enumeration of the hardware's lane groups):
 //   K tile [64][RB bytes]: 16-byte chunk c of row r at c ^ kx16(r), kx16 = (r >> 1) & 3 | r & 7 | r & 15 for RB = 64 | 128 | 256
 //   V tile [64][2 D bytes]: 32-byte block c of row r at c ^ vx16(r), vx16 = (r >> 1) & 3 (D = 64) | r & 7 (D = 128)

@@ -189,3 +189,31 @@ def test_reference_leaves_the_grid_inside_a_replay(oracle, dev, D, causal):
     assert np.abs(lse_ref).max() * 1.44269504 > 200.0
     _o_close(_np(o), o_ref)
     assert np.abs(_np(lse) - lse_ref).max() <= 1e-3 + 2.0 ** -20 * np.abs(lse_ref).max()
+
+
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("causal", [False, True])
+def test_one_wave_off_the_grid_the_others_on_it(oracle, dev, D, causal):
+    """Only the rows of ONE wave of every Q block (rows 32..63) carry the ±290-binade common mode: that wave votes for the replay and
+    replays un-rounded, the three others keep their accumulators and their rounded-scale arithmetic through the partial replay
+    (per-wave `wide`, attn_fwd16.hip)."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    S = 768
+    q, k, v = oracle.make_inputs(1, 2, S, D, seed=71)
+    rng = np.random.default_rng(13)
+    u = rng.standard_normal(D).astype(np.float32)
+    u /= np.linalg.norm(u)
+    a = 40.0 * (D / 64.0) ** 0.25
+    r = np.arange(S) % 128
+    sel = (r >= 32) & (r < 64)
+    q[:, :, sel] += a * u
+    k = k * np.repeat(rng.uniform(0.5, 2.0, S // 64), 64).astype(np.float32)[None, None, :, None] + a * u
+    q, k = oracle.to_storage(q, "fp16"), oracle.to_storage(k, "fp16")
+    tq, tk, tv = (_t(x, "fp16", dev) for x in (q, k, v))
+    o, lse = _run_twice(lambda: lb.lowbit_fa_qk_int8_pv_fp16_triton(tq, tk, tv, is_causal=causal, return_lse=True, smooth_k=False))
+    o_ref, lse_ref = oracle.lowbit_fa_forward(q, k, v, is_causal=causal, return_lse=True, smooth_k=False, amax_floor=1e-7, tail="neg_inf")
+    big = np.abs(lse_ref[0, :, sel]).min() * 1.44269504
+    small = np.abs(lse_ref[0, :, ~sel]).max() * 1.44269504
+    assert big > 150.0 and small < 100.0, (big, small)
+    _o_close(_np(o), o_ref)
+    assert np.abs(_np(lse) - lse_ref).max() <= 1e-3 + 2.0 ** -20 * np.abs(lse_ref).max()

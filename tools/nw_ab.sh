@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of the waves-per-workgroup choice of the D = 128 int8 kernels (LBFA_NW=4|8): tools/nw_ab.sh "<workloads>" [rounds]
+# A/B of the waves-per-workgroup choice of the D = 128 int8 kernels (LBFA_NW=4|8) - for the experiment build of commit c7408af only (the shipped kernels have no such switch): tools/nw_ab.sh "<workloads>" [rounds]
 wls=${1:-"d128 c3"}; rounds=${2:-2}
 for r in $(seq $rounds); do
 for nw in 4 8; do

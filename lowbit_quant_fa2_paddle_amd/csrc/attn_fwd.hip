@@ -51,6 +51,10 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
   // buffers + 16 bytes for the workgroup reduction (block amax), which must not alias a tile in flight
   __shared__ __attribute__((aligned(16))) char smem[TILES_BYTES + 16];
 
+  // P -> e4m3 must SATURATE (the reference converts with cvt.rn.satfinite.e4m3x2.f32, csrc/numeric_conversion.cuh:39-54): with the
+  // wave's MODE.FP16_OVFL clear, v_cvt_pk_fp8_f32 turns everything beyond 464 into the NaN code 0x7f; with it set, finite values
+  // clamp to +-448 (probed on gfx950, tools/fp8_sat_probe.hip).  P stays <= 448 by construction - this is the belt to those braces.
+  __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);  // hwreg(HW_REG_MODE, offset 23, 1 bit) = FP16_OVFL
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -266,25 +270,43 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
   //     s*sc - m  ==  fma(tv, sc, c1),   c1 = -kMagic*sc - m + kFp8Offset
   // The per-tile scale is rounded to a multiple of g = G/2^22, G a power of two chosen from the largest dequantisation scale
   // of this (batch, kv-head) (relative change <= 2^-21 * sc_max/sc, far below int8 quantisation noise), so kMagic*sc is exact;
-  // m is the exact row max (P_max = 448 = e4m3 max exactly, attn_utils.cuh:30) and c1 carries a rounding of <= 2^-13
-  // relative, invisible at 3 mantissa bits.
+  // m is the exact row max (P_max = 448 = e4m3 max exactly, attn_utils.cuh:30); c1 is rounded to fp32 twice, by <= ulp(kMagic sc)
+  // ~ 0.3 G in all - invisible at 3 mantissa bits while G is small.
+  // WIDE scores (round 4).  That rounding, and the 2^-19-relative rounding of the scale, stop being invisible when the scores are
+  // hundreds of binades wide - the reference's bench distribution randint(-100, 100): G = 1..2, references ~ +-5000 - : tiles drift
+  // against each other by up to 0.24 G binades, and at D = 128 (|kMagic sc| ~ 1e6, ulp 2^-4) c1 alone could lift the largest P past
+  // 464, the last value that still rounds to 448: v_cvt_pk_fp8_f32 does not saturate, it returns the NaN code, and the query's
+  // whole output row became NaN (found by tools/soak.py).  A wave therefore leaves the grid - un-rounded scale q_scale k_scale[j],
+  // bias taken off the scores with one exact subtraction each, c1 = 8.807 - m - from the start when G >= 2^-6 (kWideG), and from
+  // the tile in which one of its row maxima leaves +-2^7 binades (kGridRef) otherwise; 32 VALU more per tile where it applies.
   float ks_max = ks_first;
   for (int i = lane + 64; i < nK; i += 64) ks_max = fmaxf(ks_max, ksc[i * ksc_blk]);
   ks_max = fmaxf(wave_max_nonneg(ks_max), 1e-30f);  // scales are positive (the quantiser floors amax)
   const float sc_max = qsc * ks_max;
-  const int gexp = (int)((__float_as_uint(1.25f * kMagic * sc_max) >> 23) & 0xff) - 127 + 1 - 21;  // log2(G)
+  const int gexp = __builtin_amdgcn_readfirstlane((int)((__float_as_uint(1.25f * kMagic * sc_max) >> 23) & 0xff) - 127 + 1 - 21);  // log2(G)
   const float g = __builtin_ldexpf(1.0f, gexp - 22), invg = __builtin_ldexpf(1.0f, 22 - gexp);
+  constexpr int kWideG = -6;            // log2 of the grid step from which every tile dequantises un-rounded
+  constexpr float kGridRef = 128.0f;    // |row max| (binades) beyond which a wave leaves the grid (as attn_fwd16.hip)
+  bool wide = gexp >= kWideG;           // wave-uniform; only ever switched on
   // Per-tile constants sc (dequantisation scale on the g grid) and c0 = -kMagic * sc are the same for every lane: lane l
   // of the wave computes them for tile 64 c + l once per chunk of 64 tiles, and each tile fetches its pair with two
   // v_readlane (no per-tile global load, no per-tile float math on uniform values).
-  float sc_tab = 0.f, c0_tab = 0.f;
+  // (sc_tab, c0_tab: the scale and the bias constant as the tile loop uses them - on the grid, or un-rounded and 0 for a `wide`
+  // wave; ks_tab: the raw k_scale, from which a wave that leaves the grid in the middle of its tiles rebuilds them without a memory
+  // access)
+  float sc_tab = 0.f, c0_tab = 0.f, ks_tab = 0.f;
   auto refresh_scale_table = [&](int j0) __attribute__((always_inline)) {
     const int jt = j0 + lane;
     const float ks_l = j0 == 0 ? ks_first : (jt < nK ? ksc[jt * ksc_blk] : 0.f);
+    ks_tab = ks_l;
     // at least one grid step: a block whose scale is < 2^-22 of the largest one (an all-zero K block) must not get
     // sc = 0, or a masked key (tv = -inf) would turn into fma(-inf, 0, c1) = NaN
     sc_tab = fmaxf(__builtin_rintf(qsc * ks_l * invg), 1.0f) * g;
     c0_tab = -kMagic * sc_tab;  // exact
+    if (wide) {
+      sc_tab = fmaxf(qsc * ks_l, 1e-30f);
+      c0_tab = 0.f;
+    }
   };
 
   // One 64-key tile.
@@ -293,8 +315,8 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
     constexpr bool MASKED = decltype(masked_tag)::value;
     const char* kbuf = smem + BUF * KBYTES;
     const char* vbuf = smem + BUF * VBYTES;
-    const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc_tab), j & 63));
-    const float c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c0_tab), j & 63));
+    float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc_tab), j & 63));
+    float c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c0_tab), j & 63));
     float x[2][16];  // scores as floats kMagic + s (accumulator bits), overwritten in place by P
     // -- S^T = K Q^T (int8 -> int32, biased by kMagic): one 32-key block
     auto compute_scores = [&](auto kb2_tag) __attribute__((always_inline)) {
@@ -337,9 +359,37 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
         tmax = key_max<true>(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
       }
-      const float xmax = __builtin_fmaf(tmax, sc, c0);  // row max of the dequantised scores; -inf if all masked
-      const float m_cand = fmaxf(m_run, xmax);
+      // Row max of the dequantised scores (-inf if all masked).  ONE wave-uniform branch separates the two arithmetics: on the grid
+      // the tile runs exactly round 3's instructions; a `wide` wave takes the bias off its scores here, once, for the max and for
+      // the exponentials below.
+      auto unbias = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) x[kb2][i] -= kMagic;  // exact; -inf stays -inf
+      };
+      float xmax;
+      if (wide) {
+        unbias();
+        xmax = (tmax - kMagic) * sc;  // exact integer times the un-rounded scale
+      } else {
+        xmax = __builtin_fmaf(tmax, sc, c0);
+      }
+      float m_cand = fmaxf(m_run, xmax);
       if (__any(m_cand > m_run)) {
+        if (!wide) {  // wave-uniform: does the new row maximum leave the range in which the grid is exact enough?
+          const float ra = __builtin_fabsf(m_cand);
+          if (__any(ra > kGridRef && ra < INFINITY)) {
+            wide = true;  // this tile and every later one of the wave (the earlier ones had all their maxima inside the range)
+            sc_tab = fmaxf(qsc * ks_tab, 1e-30f);
+            c0_tab = 0.f;
+            sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc_tab), j & 63));
+            c0 = 0.f;
+            unbias();
+            xmax = (tmax - kMagic) * sc;
+            m_cand = fmaxf(m_run, xmax);
+          }
+        }
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);  // m_run = -inf -> 0
         m_run = m_cand;
         l_run *= alpha;

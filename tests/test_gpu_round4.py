@@ -234,3 +234,42 @@ def test_randint_on_one_to_three_tiles(oracle, dev, S, D, causal):
     o_ref, lse_ref = oracle.lowbit_fa_forward(q, k, v, is_causal=causal, return_lse=True, amax_floor=1e-7, tail="neg_inf")
     _o_close(_np(o), o_ref)
     assert np.abs(_np(lse) - lse_ref).max() <= 1e-3 + 2.0 ** -10 * np.abs(lse_ref).max()
+
+
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("causal", [False, True])
+def test_fp8_pv_on_the_bench_distribution(oracle, dev, D, causal):
+    """qk_int8_pv_fp8 on q, k = randint(-100, 100): before round 4 the fp8 kernel kept these scores on its rounded-scale grid -
+    tiles drifted against each other by a fraction of a binade, 30 % of the rows missed the per-element bound by 3..4 % (a
+    common factor per row: e4m3(P) / P of the dominant key) - it now dequantises them un-rounded (attn_fwd.hip, `wide`).
+    fp8-PV parity itself stays unpinned: this is the HIP path against the oracle's restatement."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    from test_gpu_parity import _fp8_close
+    q, k, v = oracle.make_inputs(1, 2, 512, D, seed=5, dist="randint")
+    tq, tk, tv = (_t(x, "fp16", dev) for x in (q, k, v))
+    o, lse = _run_twice(lambda: lb.lowbit_fa_qk_int8_pv_fp8_cuda(tq, tk, tv, is_causal=causal, return_lse=True))
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    o_ref, lse_ref = oracle.lowbit_fa_forward(q, k, v, is_causal=causal, return_lse=True, pv="fp8", amax_floor=1e-7)
+    _fp8_close(_np(o), o_ref)
+    assert np.abs(_np(lse) - lse_ref).max() <= 2e-3 + 2.0 ** -10 * np.abs(lse_ref).max()
+
+
+def test_fp8_pv_largest_p_never_leaves_the_e4m3_range(oracle, dev):
+    """B1 H8 S2048 D128 randint (the configuration in which tools/soak.py found it): at D = 128 the bias constant of the one-fma
+    form is ~1e6, its fp32 ulp 2^-4 binades, and two roundings of it could lift a row's largest P from 448 past 464 - the last
+    value that still rounds to 448; v_cvt_pk_fp8_f32 returns the NaN code beyond it, and the query's whole output row was NaN.
+    Every output finite, and the head that failed against the oracle."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    from test_gpu_parity import _fp8_close
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    B, H, S, D = 1, 8, 2048, 128
+    q = torch.randint(-100, 100, (B, H, S, D), generator=g, device=dev).half()
+    k = torch.randint(-100, 100, (B, H, S, D), generator=g, device=dev).half()
+    v = torch.randn((B, H, S, D), generator=g, device=dev).half()
+    o, lse = lb.lowbit_fa_qk_int8_pv_fp8_cuda(q, k, v, return_lse=True)
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    h = 7
+    qn, kn, vn = (x[:, h:h + 1].float().cpu().numpy() for x in (q, k, v))
+    o_ref = oracle.lowbit_fa_forward(qn, kn, vn, pv="fp8", amax_floor=1e-7)
+    _fp8_close(_np(o[:, h:h + 1]), o_ref)

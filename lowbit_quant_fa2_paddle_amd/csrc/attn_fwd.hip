@@ -317,6 +317,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
     const char* vbuf = smem + BUF * VBYTES;
     float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc_tab), j & 63));
     float c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c0_tab), j & 63));
+    const float bias = wide ? kMagic : 0.f;  // wave-uniform (scalar select)
     float x[2][16];  // scores as floats kMagic + s (accumulator bits), overwritten in place by P
     // -- S^T = K Q^T (int8 -> int32, biased by kMagic): one 32-key block
     auto compute_scores = [&](auto kb2_tag) __attribute__((always_inline)) {
@@ -359,22 +360,8 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
         tmax = key_max<true>(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
       }
-      // Row max of the dequantised scores (-inf if all masked).  ONE wave-uniform branch separates the two arithmetics: on the grid
-      // the tile runs exactly round 3's instructions; a `wide` wave takes the bias off its scores here, once, for the max and for
-      // the exponentials below.
-      auto unbias = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) x[kb2][i] -= kMagic;  // exact; -inf stays -inf
-      };
-      float xmax;
-      if (wide) {
-        unbias();
-        xmax = (tmax - kMagic) * sc;  // exact integer times the un-rounded scale
-      } else {
-        xmax = __builtin_fmaf(tmax, sc, c0);
-      }
+      // row max of the dequantised scores (-inf if all masked); bias, c0 = 0, -kMagic sc on the grid, kMagic, 0 for a `wide` wave
+      float xmax = __builtin_fmaf(tmax - bias, sc, c0);
       float m_cand = fmaxf(m_run, xmax);
       if (__any(m_cand > m_run)) {
         if (!wide) {  // wave-uniform: does the new row maximum leave the range in which the grid is exact enough?
@@ -385,8 +372,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
             c0_tab = 0.f;
             sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc_tab), j & 63));
             c0 = 0.f;
-            unbias();
-            xmax = (tmax - kMagic) * sc;
+            xmax = (tmax - kMagic) * sc;  // exact integer times the un-rounded scale
             m_cand = fmaxf(m_run, xmax);
           }
         }
@@ -400,6 +386,12 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
       }
     }
     const float c1 = c0 - m_run + kFp8Offset;  // +inf while m_run = -inf
+    if (wide) {  // wave-uniform: scores as the integers themselves (-inf stays -inf)
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[kb2][i] -= kMagic;
+    }
     // V^T fragment of channel block 0: requested here, in flight under the exponentials
     i32x4 vnext[2][2];
     vnext[0][0] = *reinterpret_cast<const i32x4*>(vbuf + vf_base);

@@ -51,10 +51,6 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
   // buffers + 16 bytes for the workgroup reduction (block amax), which must not alias a tile in flight
   __shared__ __attribute__((aligned(16))) char smem[TILES_BYTES + 16];
 
-  // P -> e4m3 must SATURATE (the reference converts with cvt.rn.satfinite.e4m3x2.f32, csrc/numeric_conversion.cuh:39-54): with the
-  // wave's MODE.FP16_OVFL clear, v_cvt_pk_fp8_f32 turns everything beyond 464 into the NaN code 0x7f; with it set, finite values
-  // clamp to +-448 (probed on gfx950, tools/fp8_sat_probe.hip).  P stays <= 448 by construction - this is the belt to those braces.
-  __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);  // hwreg(HW_REG_MODE, offset 23, 1 bit) = FP16_OVFL
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -475,6 +471,12 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
 
   refresh_scale_table(tile_of(0) & ~63);
   __syncthreads();
+  // P -> e4m3 must SATURATE (the reference converts with cvt.rn.satfinite.e4m3x2.f32, csrc/numeric_conversion.cuh:39-54): with the
+  // wave's MODE.FP16_OVFL clear, v_cvt_pk_fp8_f32 turns everything beyond 464 into the NaN code 0x7f; with it set, finite values
+  // clamp to +-448 (probed on gfx950, tools/fp8_sat_probe.hip).  P stays <= 448 by construction - this is the belt to those braces.
+  // The bit is set for the TILE LOOP only: it also makes fp32 -> fp16 conversions clamp instead of overflowing to inf, and the
+  // prologue's q . km (rounded to the storage dtype, src/core.py:294-304) and the epilogue's stores overflow as the reference's do.
+  __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);  // hwreg(HW_REG_MODE, offset 23, 1 bit) = FP16_OVFL
   {
     int j = 0;
     for (; j + 1 < n_main; j += 2) {
@@ -491,6 +493,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
       }
     }
   }
+  __builtin_amdgcn_s_setreg(1 | (23 << 6), 0);  // fp16 overflow semantics back to the default for the epilogue
   const float l_tot = half_swap_sum(l_run);
 
   // ---- epilogue: O = O^T / l x v_scale, LSE ------------------------------------------------------------

@@ -273,3 +273,27 @@ def test_fp8_pv_largest_p_never_leaves_the_e4m3_range(oracle, dev):
     qn, kn, vn = (x[:, h:h + 1].float().cpu().numpy() for x in (q, k, v))
     o_ref = oracle.lowbit_fa_forward(qn, kn, vn, pv="fp8", amax_floor=1e-7)
     _fp8_close(_np(o[:, h:h + 1]), o_ref)
+
+
+@pytest.mark.parametrize("op", ["int8", "fp8"])
+@pytest.mark.parametrize("D", [64, 128])
+def test_lse_overflows_exactly_where_the_reference_overflows(oracle, dev, op, D):
+    """q, k ~ 1000 N(0,1) in fp16: the reference rounds `lse_correction = q . km` to the storage dtype (src/core.py:294-304), which
+    overflows fp16 for most rows - its LSE is inf there and so must this one be, row for row (the fp8 kernel runs its tile loop with the
+    mode bit that clamps fp16 overflows set; prologue and epilogue must not); O stays finite and, on these one-hot rows, equal to
+    the oracle's for the fp16-P operator."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    rng = np.random.default_rng(D)
+    q, k, v = (rng.standard_normal((1, 2, 640, D)).astype(np.float32) for _ in range(3))
+    q, k, v = oracle.to_storage(q * 1000.0, "fp16"), oracle.to_storage(k * 1000.0, "fp16"), oracle.to_storage(v, "fp16")
+    tq, tk, tv = (_t(x, "fp16", dev) for x in (q, k, v))
+    fn = lb.lowbit_fa_qk_int8_pv_fp16_triton if op == "int8" else lb.lowbit_fa_qk_int8_pv_fp8_cuda
+    o, lse = fn(tq, tk, tv, return_lse=True)
+    with np.errstate(all="ignore"):
+        o_ref, lse_ref = oracle.lowbit_fa_forward(q, k, v, return_lse=True, amax_floor=1e-7, **({"pv": "fp8"} if op == "fp8" else {"tail": "neg_inf"}))
+    assert torch.isfinite(o).all() and np.isfinite(o_ref).all()
+    bad, bad_ref = ~np.isfinite(_np(lse)), ~np.isfinite(lse_ref)
+    assert bad_ref.sum() > 100 and np.array_equal(bad, bad_ref)
+    assert np.array_equal(np.sign(_np(lse)[bad]), np.sign(lse_ref[bad]))
+    if op == "int8":
+        _o_close(_np(o), o_ref)

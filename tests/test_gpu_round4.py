@@ -297,3 +297,25 @@ def test_lse_overflows_exactly_where_the_reference_overflows(oracle, dev, op, D)
     assert np.array_equal(np.sign(_np(lse)[bad]), np.sign(lse_ref[bad]))
     if op == "int8":
         _o_close(_np(o), o_ref)
+
+
+@pytest.mark.parametrize("D,Hq,Hkv", [(64, 2, 2), (128, 4, 2)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_varlen_on_the_bench_distribution(oracle, dev, D, Hq, Hkv, causal):
+    """Packed variable-length batches of q, k = randint(-100, 100): sequences of 1 key tile up to 9, ragged tails, a one-token
+    sequence - every one of them leaves the scale grid (the packed path shares the tile loop, its votes and its replay)."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    lens = [300, 1, 64, 577, 130]
+    rng = np.random.default_rng(91)
+    tot = sum(lens)
+    q = oracle.to_storage(rng.integers(-100, 100, (tot, Hq, D)).astype(np.float32), "fp16")
+    k = oracle.to_storage(rng.integers(-100, 100, (tot, Hkv, D)).astype(np.float32), "fp16")
+    v = oracle.to_storage(rng.standard_normal((tot, Hkv, D)).astype(np.float32), "fp16")
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    tq, tk, tv = (_t(x, "fp16", dev) for x in (q, k, v))
+    tcu = torch.from_numpy(cu).to(dev)
+    o = lb.lowbit_fa_varlen(tq, tk, tv, tcu, tcu, max(lens), max(lens), is_causal=causal)
+    o2 = lb.lowbit_fa_varlen(tq, tk, tv, tcu, tcu, max(lens), max(lens), is_causal=causal)
+    assert torch.isfinite(o).all() and torch.equal(o, o2)
+    o_ref = oracle.lowbit_fa_varlen(q, k, v, cu, cu, is_causal=causal, amax_floor=1e-7, tail="neg_inf")
+    _o_close(_np(o), o_ref)

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
   // halves are added once, in the epilogue.
   f32x16 acc_o[DB];
   float m_run = -INFINITY;  // running row max (base-2 domain), identical in both halves of a row
+  float m_lo = 0.f;         // `wide` waves: the row max is the exact product (integer score) x (scale) = m_run + m_lo (see below)
   float l_run = 0.f;
 #pragma unroll
   for (int db = 0; db < DB; ++db)
@@ -284,6 +285,8 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
   constexpr int kWideG = -6;            // log2 of the grid step from which every tile dequantises un-rounded
   constexpr float kGridRef = 128.0f;    // |row max| (binades) beyond which a wave leaves the grid (as attn_fwd16.hip)
   bool wide = gexp >= kWideG;           // wave-uniform; only ever switched on
+  constexpr float kHugeRef = 0x1p16f;   // |row max| (binades) beyond which a `wide` wave re-references its scores (compute_tile)
+  bool huge = false;                    // wave-uniform; only ever switched on
   // Per-tile constants sc (dequantisation scale on the g grid) and c0 = -kMagic * sc are the same for every lane: lane l
   // of the wave computes them for tile 64 c + l once per chunk of 64 tiles, and each tile fetches its pair with two
   // v_readlane (no per-tile global load, no per-tile float math on uniform values).
@@ -372,7 +375,18 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
             m_cand = fmaxf(m_run, xmax);
           }
         }
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);  // m_run = -inf -> 0
+        float dlo = 0.f;
+        if (wide) {  // the rows that take this tile's maximum keep what the product lost when it was rounded to m_run
+          const float lo = __builtin_fmaf(tmax - kMagic, sc, -xmax);  // exact (NaN for a row without keys: never selected)
+          const float lo_new = xmax > m_run ? lo : m_lo;
+          dlo = m_lo - lo_new;
+          m_lo = lo_new;
+          if (!huge) {
+            const float ra = __builtin_fabsf(m_cand);
+            huge = __any(ra > kHugeRef && ra < INFINITY) != 0;
+          }
+        }
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_cand) + dlo);  // m_run = -inf -> 0
         m_run = m_cand;
         l_run *= alpha;
 #pragma unroll
@@ -381,12 +395,25 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
           for (int i = 0; i < 16; ++i) acc_o[db][i] *= alpha;
       }
     }
-    const float c1 = c0 - m_run + kFp8Offset;  // +inf while m_run = -inf
+    float c1 = c0 - m_run + kFp8Offset;  // +inf while m_run = -inf
     if (wide) {  // wave-uniform: scores as the integers themselves (-inf stays -inf)
+      float bias_r = kMagic;
+      if (huge) {
+        // ... as integers RELATIVE TO THE ROW'S REFERENCE, in this tile's units.  The reference of a row is an exact product
+        // t x sc of some earlier tile, kept as m_run + m_lo; with r = the integer nearest to it in this tile's units,
+        //     s sc - m = (s - r) sc + (r sc - m_run - m_lo):
+        // the first product is small where P is not, the bracket is the remainder of one fma.  One fma against the ROUNDED m_run
+        // leaves P_max = 448 x 2^(rounding of m_run): beyond |m_run| ~ 2^19 binades (q, k some hundred times N(0,1)) that is
+        // percents of P, saturated away by the conversion while the row sum keeps them; below kHugeRef it is < 0.3 % and the plain
+        // form stays.  |r| <= 2^22 keeps kMagic + r exact; a clamped r only gives up the precision, where P = 0 anyway.
+        const float r = __builtin_amdgcn_fmed3f(__builtin_rintf(m_run * __builtin_amdgcn_rcpf(sc)), -0x1p22f, 0x1p22f);
+        bias_r = kMagic + r;
+        c1 = (__builtin_fmaf(r, sc, -m_run) - m_lo) + kFp8Offset;
+      }
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) x[kb2][i] -= kMagic;
+        for (int i = 0; i < 16; ++i) x[kb2][i] -= bias_r;
     }
     // V^T fragment of channel block 0: requested here, in flight under the exponentials
     i32x4 vnext[2][2];

@@ -297,6 +297,32 @@ def test_lse_overflows_exactly_where_the_reference_overflows(oracle, dev, op, D)
     assert np.array_equal(np.sign(_np(lse)[bad]), np.sign(lse_ref[bad]))
     if op == "int8":
         _o_close(_np(o), o_ref)
+    else:  # (before the fp8 kernel re-referenced such scores - next test - 73 % of these rows missed the bound, by up to 11 x)
+        from test_gpu_parity import _fp8_close
+        _fp8_close(_np(o), o_ref)
+
+
+@pytest.mark.parametrize("dt,mul", [("fp16", 300.0), ("fp16", 1000.0), ("fp16", 1e4), ("bf16", 1e5), ("bf16", 1e7)])
+@pytest.mark.parametrize("D,causal", [(64, False), (128, True)])
+def test_fp8_pv_on_scores_millions_of_binades_wide(oracle, dev, dt, mul, D, causal):
+    """q, k = mul x N(0,1): softmax references of 1e5 .. 1e15 binades.  One fma `s sc - m` against the reference ROUNDED to fp32 leaves
+    the largest P of a row at 448 x 2^(that rounding) - percents of P from |m| ~ 2^19 on, whole binades beyond 2^24 - which the e4m3
+    conversion saturates away while the fp32 row sum keeps it: rows came out scaled down by up to 1/3 (x1000), LSE non-finite at
+    x1e5.  The fp8 kernel now keeps the reference as an exact product (m_run + m_lo) and takes the scores relative to it
+    (attn_fwd.hip, `huge`): these rows are one-hot or nearly so and must match the oracle's restatement element for element."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    from test_gpu_parity import _fp8_close
+    rng = np.random.default_rng(int(mul) % 1000 + D)
+    q, k, v = (rng.standard_normal((1, 2, 640, D)).astype(np.float32) for _ in range(3))
+    q, k, v = oracle.to_storage(q * mul, dt), oracle.to_storage(k * mul, dt), oracle.to_storage(v, dt)
+    tq, tk, tv = (_t(x, dt, dev) for x in (q, k, v))
+    o, lse = _run_twice(lambda: lb.lowbit_fa_qk_int8_pv_fp8_cuda(tq, tk, tv, is_causal=causal, return_lse=True, smooth_k=False))
+    with np.errstate(all="ignore"):
+        o_ref, lse_ref = oracle.lowbit_fa_forward(q, k, v, dtype=dt, is_causal=causal, return_lse=True, smooth_k=False, pv="fp8", amax_floor=1e-7)
+    assert np.isfinite(o_ref).all() and np.isfinite(lse_ref).all()
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    _fp8_close(_np(o), o_ref)
+    assert np.abs(_np(lse) - lse_ref).max() <= 2.0 ** -20 * np.abs(lse_ref).max()
 
 
 @pytest.mark.parametrize("D,Hq,Hkv", [(64, 2, 2), (128, 4, 2)])

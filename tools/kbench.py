@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--cfg", nargs="*", default=["c2", "d128", "c2c", "c3", "f8d64"])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--dist", default="normal", choices=["normal", "randint"], help="randint: the reference's bench distribution randint(-100, 100)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     for name in a.cfg:
@@ -46,6 +47,8 @@ def main():
         q = torch.randn(shp, generator=g, device=dev).half()
         k = torch.randn(shp, generator=g, device=dev).half()
         v = torch.randn(shp, generator=g, device=dev).half()
+        if a.dist == "randint":
+            q, k, v = (torch.randint(-100, 100, shp, generator=g, device=dev).half() for _ in range(3))
         if pv == "qk16":
             from lowbit_quant_fa2_paddle_amd import core
             f = lambda: (core.flash_attn_fp16(q, k, v, tensor_layout=layout, is_causal=causal), None)

@@ -376,14 +376,15 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
           }
         }
         float dlo = 0.f;
-        if (wide) {  // the rows that take this tile's maximum keep what the product lost when it was rounded to m_run
-          const float lo = __builtin_fmaf(tmax - kMagic, sc, -xmax);  // exact (NaN for a row without keys: never selected)
-          const float lo_new = xmax > m_run ? lo : m_lo;
-          dlo = m_lo - lo_new;
-          m_lo = lo_new;
-          if (!huge) {
-            const float ra = __builtin_fabsf(m_cand);
-            huge = __any(ra > kHugeRef && ra < INFINITY) != 0;
+        if (wide) {
+          // (one compare: a row that has not seen a key yet, m_cand = -inf, switches the wave too - that costs time, nothing else)
+          if (!huge) huge = __any(__builtin_fabsf(m_cand) > kHugeRef) != 0;
+          if (huge) {  // the rows that take this tile's maximum keep what the product lost when it was rounded to m_run
+            // (references taken before the switch keep m_lo = 0: they were below kHugeRef, their remainder below 2^-9 binades)
+            const float lo = __builtin_fmaf(tmax - kMagic, sc, -xmax);  // exact (NaN for a row without keys: never selected)
+            const float lo_new = xmax > m_run ? lo : m_lo;
+            dlo = m_lo - lo_new;
+            m_lo = lo_new;
           }
         }
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_cand) + dlo);  // m_run = -inf -> 0

@@ -345,3 +345,44 @@ def test_varlen_on_the_bench_distribution(oracle, dev, D, Hq, Hkv, causal):
     assert torch.isfinite(o).all() and torch.equal(o, o2)
     o_ref = oracle.lowbit_fa_varlen(q, k, v, cu, cu, is_causal=causal, amax_floor=1e-7, tail="neg_inf")
     _o_close(_np(o), o_ref)
+
+
+@pytest.mark.parametrize("op", ["int8", "int4", "fp8", "sdpa16"])
+@pytest.mark.parametrize("D", [64, 96, 128])
+def test_strided_operands_give_the_bits_of_contiguous_ones(dev, op, D):
+    """q, k, v as views with a batch, head or token stride of their own (a slice of a fused projection output, every second token
+    of a cache, every second head): operands go to the C ABI as strides (attn_qk_int8_per_block.py:183-196), no copy is made, and
+    O and LSE are bit for bit those of the contiguous call."""
+    import lowbit_quant_fa2_paddle_amd as lb
+    from lowbit_quant_fa2_paddle_amd import core
+    g = torch.Generator(device=dev)
+    g.manual_seed(D)
+    B, H, S = 2, 4, 333
+    fn = {"int8": lambda q, k, v: lb.lowbit_fa_qk_int8_pv_fp16_triton(q, k, v, is_causal=True, return_lse=True),
+          "int4": lambda q, k, v: lb.lowbit_fa_qk_int4_pv_fp16_triton(q, k, v, return_lse=True),
+          "fp8": lambda q, k, v: lb.lowbit_fa_qk_int8_pv_fp8_cuda(q, k, v, return_lse=True),
+          "sdpa16": lambda q, k, v: core.flash_attn_fp16(q, k, v, is_causal=True, return_lse=True)}[op]
+    q, k, v = (torch.randn((B, H, S, D), generator=g, device=dev).half() for _ in range(3))
+
+    def batch_strided(x):
+        buf = torch.zeros((B, 3, H, S, D), device=dev, dtype=x.dtype)
+        buf[:, 1] = x
+        return buf[:, 1]
+
+    def token_strided(x):
+        buf = torch.zeros((B, H, 2 * S, D), device=dev, dtype=x.dtype)
+        buf[:, :, 1::2] = x
+        return buf[:, :, 1::2]
+
+    def head_strided(x):
+        buf = torch.zeros((B, 2 * H, S, D), device=dev, dtype=x.dtype)
+        buf[:, ::2] = x
+        return buf[:, ::2]
+
+    o0, lse0 = fn(q, k, v)
+    assert torch.isfinite(o0).all()
+    for views in ((batch_strided(q), token_strided(k), head_strided(v)), (token_strided(q), head_strided(k), batch_strided(v)),
+                  (head_strided(q), batch_strided(k), token_strided(v))):
+        assert not any(t.is_contiguous() for t in views)
+        o, lse = fn(*views)
+        assert torch.equal(o, o0) and torch.equal(lse, lse0)

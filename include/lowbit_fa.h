@@ -171,6 +171,10 @@ int lbfa_profile_next_attn(void* start_event, void* stop_event);
  *             channels and treat the missing ones as the zero padding of src/core.py:277-287 (never read, never
  *             written), so the host makes no padded copies; results are bit-identical to padding on the host.
  *             (lbfa_forward_varlen likewise; the modular entry points take D in {64, 128} only.)
+ *   range   : scores s = q.k * sm_scale * log2(e) of any size with pv_fp8 (the kernel keeps its softmax reference as an exact
+ *             product once it passes 2^16); with fp16 P (pv_fp8 = 0) up to |s| < 2^27 - q, k of a few thousand times N(0,1):
+ *             beyond it the exponent's one fma `s sc - m` against the rounded reference can overflow fp16 P (rows of NaN), as
+ *             in every FlashAttention-2 kernel, lbfa_sdpa_fwd included.
  */
 size_t lbfa_forward_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int pv_fp8, int smooth_k, int return_lse);
 size_t lbfa_forward_workspace_bytes_dt(int B, int Hq, int Hkv, int Sq, int Sk, int D, int dtype, int pv_fp8, int smooth_k,

@@ -34,6 +34,36 @@ namespace lbfa {
 // block scales: twice the fp16 MFMA rate) - must match the V layout written by lbfa_quant_v_fp8 (quant_kernels.hip)
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
+#if defined(LBFA_STAMPS8)  // diagnostic build only (-DLBFA_STAMPS8, tools/stamps8.py): s_memtime at points of a workgroup's life, thread 0
+// record per workgroup: [0..4] kernel entry, tile loop start, tile loop end, stores issued; [8..15] progress of wave 0's
+// instruction stream through ONE unmasked tile (the middle one): step top, tile fetch issued, QK^T issued, row max + rescale done,
+// exponentials + conversions issued, PV issued, barrier passed; [16], [17]: s_memrealtime (100 MHz) around the tile loop
+__device__ long long g_stamps8[8192 * 24];
+#define LBFA8_STAMP(k)                                                                                            \
+  do {                                                                                                            \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps8[blockIdx.x * 24 + (k)] = __builtin_amdgcn_s_memtime();   \
+  } while (0)
+#define LBFA8_RSTAMP(k)                                                                                               \
+  do {                                                                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps8[blockIdx.x * 24 + (k)] = __builtin_amdgcn_s_memrealtime();   \
+  } while (0)
+#define LBFA8_TSTAMP(k)                                     \
+  do {                                                      \
+    __builtin_amdgcn_sched_barrier(0);                      \
+    if (ts_on) ts[k] = __builtin_amdgcn_s_memtime();        \
+    __builtin_amdgcn_sched_barrier(0);                      \
+  } while (0)
+}  // namespace lbfa
+extern "C" int lbfa_debug_stamps8(void* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(lbfa::g_stamps8), sizeof(lbfa::g_stamps8), 0, hipMemcpyDeviceToHost);
+}
+namespace lbfa {
+#else
+#define LBFA8_STAMP(k)
+#define LBFA8_RSTAMP(k)
+#define LBFA8_TSTAMP(k)
+#endif
+
 
 // OT = dtype of O (and of the Q source when QQ): int8 Q / K codes, e4m3 V; QQ = Q is quantised inside the kernel
 template <int D, int OT, bool CAUSAL, bool QQ = false>
@@ -55,6 +85,9 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int r = lane & 31, hh = lane >> 5;
+  LBFA8_STAMP(0);
+  [[maybe_unused]] long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  [[maybe_unused]] bool ts_on = false;
 
   // ---- which (batch, head, q-block) -----------------------------------------------------------------
   const unsigned w_id = xcd_remap(blockIdx.x, gridDim.x);
@@ -342,6 +375,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
     };
     compute_scores(std::integral_constant<int, 0>{});
     compute_scores(std::integral_constant<int, 1>{});
+    LBFA8_TSTAMP(2);
     // -- online softmax, base 2: move m_run up to this tile's row max, rescaling O and l, when some row of the wave needs it
     // (first tile: m_run = -inf -> alpha = 0)
     {
@@ -396,6 +430,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
           for (int i = 0; i < 16; ++i) acc_o[db][i] *= alpha;
       }
     }
+    LBFA8_TSTAMP(3);
     float c1 = c0 - m_run + kFp8Offset;  // +inf while m_run = -inf
     if (wide) {  // wave-uniform: scores as the integers themselves (-inf stays -inf)
       float bias_r = kMagic;
@@ -448,6 +483,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
     }
     __builtin_amdgcn_sched_barrier(0);  // phase fence: keeps the V fragment reads and the row-sum adds where they are (registers)
     l_run += psum;
+    LBFA8_TSTAMP(4);
     // -- O^T += V^T P^T: e4m3 x e4m3 (cbsz = blgp = 0), E8M0 block scales 0x7F = 2^0.  The V^T fragment of channel block db + 1 is
     // requested before the MFMA of block db is issued (the first one before the exponentials, see above): a 16-pass MFMA covers the
     // LDS round trip of the next operand instead of waiting for its own.
@@ -489,12 +525,19 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
   using Yes = std::true_type;
   auto step = [&](auto buf_tag, auto nbuf_tag, int i, auto masked_tag) __attribute__((always_inline)) {
     const int j = tile_of(i);
+#if defined(LBFA_STAMPS8)
+    ts_on = !decltype(masked_tag)::value && i == (n_main >> 1) && wave == 0;
+#endif
+    LBFA8_TSTAMP(0);
     if (i != 0 && (j & 63) == (rev ? 63 : 0)) refresh_scale_table(j & ~63);  // wave-uniform: entering the next chunk of 64 tiles
     load_tile(tile_of(i + 1), nbuf_tag);
+    LBFA8_TSTAMP(1);
     bool skip = false;
     if constexpr (decltype(masked_tag)::value && CAUSAL) skip = j * 64 > row0 + 31;  // all keys above all rows of this wave
     if (!skip) compute_tile(buf_tag, j, masked_tag);
+    LBFA8_TSTAMP(5);
     __syncthreads();  // with LDS-DMA in flight this waits vmcnt(0) first: tile j + 1 has landed when the barrier opens
+    LBFA8_TSTAMP(6);
   };
 
   refresh_scale_table(tile_of(0) & ~63);
@@ -505,6 +548,8 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
   // The bit is set for the TILE LOOP only: it also makes fp32 -> fp16 conversions clamp instead of overflowing to inf, and the
   // prologue's q . km (rounded to the storage dtype, src/core.py:294-304) and the epilogue's stores overflow as the reference's do.
   __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);  // hwreg(HW_REG_MODE, offset 23, 1 bit) = FP16_OVFL
+  LBFA8_STAMP(1);
+  LBFA8_RSTAMP(16);
   {
     int j = 0;
     for (; j + 1 < n_main; j += 2) {
@@ -521,6 +566,8 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
       }
     }
   }
+  LBFA8_STAMP(2);
+  LBFA8_RSTAMP(17);
   __builtin_amdgcn_s_setreg(1 | (23 << 6), 0);  // fp16 overflow semantics back to the default for the epilogue
   const float l_tot = half_swap_sum(l_run);
 
@@ -552,6 +599,11 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
       p.lse[li] = ls;
     }
   }
+  LBFA8_STAMP(3);
+#if defined(LBFA_STAMPS8)
+  if (threadIdx.x == 0 && blockIdx.x < 8192)
+    for (int k = 0; k < 8; ++k) g_stamps8[blockIdx.x * 24 + 8 + k] = ts[k];
+#endif
 }
 
 // ---- launchers: every fp16-P variant runs in attn_fwd16.hip, fp8 PV here ------------------------------------------
